@@ -1,0 +1,164 @@
+/* rvb_capi.h — C-ABI of the MI355X-native acoustic ray tracer (librvb_hip.so).
+ *
+ * This is the drop-in boundary for the reference's per-ray hot path.  The reference has no
+ * FFI of its own for this path: its callers (cmd/main.cpp:241-298 and the gtest fixtures)
+ * use the C++ classes of rayverb/rayverb.h directly, which in turn drive three OpenCL
+ * kernels.  Each entry point below names the reference interface it replaces; the C++ mirror
+ * of those classes (include/rayverb/rayverb.h, built on nothing but this header) is what a
+ * maintainer links instead of the OpenCL-backed library — see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns RVB_OK (0) or an RVB_ERR_* code; rvb_last_error() gives the text
+ *     (the reference throws cl::Error / std::runtime_error instead, rayverb.cpp:151-192);
+ *   - all pointers are caller-owned; "host" pointers are ordinary memory, "device" pointers are
+ *     HBM addresses on the context's GPU (e.g. torch.Tensor.data_ptr());
+ *   - PODs are layout-identical to reference rayverb/clstructs.h (sizes in SURVEY.md §8(a));
+ *     this header demands no particular alignment of host buffers;
+ *   - a context is bound to one GPU and one HIP stream and is not thread-safe (the reference's
+ *     objects are not either: one in-order queue per KernelLoader, rayverb.cpp:191);
+ *   - there is no CPU fallback: without a usable gfx950 device rvb_create() fails.
+ */
+#ifndef RVB_CAPI_H
+#define RVB_CAPI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RVB_NUM_IMAGE_SOURCE 10   /* reference rayverb/clstructs.h:4 */
+#define RVB_NUM_BANDS 8           /* VolumeType = cl_float8, reference rayverb/clstructs.h:13 */
+
+enum {
+    RVB_OK = 0,
+    RVB_ERR_INVALID = 1,     /* bad argument */
+    RVB_ERR_NO_DEVICE = 2,   /* no usable gfx950 GPU / HIP runtime failure at start-up */
+    RVB_ERR_HIP = 3,         /* a HIP call failed */
+    RVB_ERR_STATE = 4,       /* call order (e.g. trace before set_scene) */
+    RVB_ERR_CAPACITY = 5     /* caller buffer too small / scene exceeds a built-in limit */
+};
+
+/* reference rayverb/clstructs.h:17-24 (Triangle), :27-32 (Surface), :36-42 (Impulse),
+ * :44-49 (AttenuatedImpulse), :53-58 (Speaker); cl_float3 is a 16-byte float4. */
+typedef struct { uint64_t surface, v0, v1, v2; } rvb_triangle;                          /* 32 B */
+typedef struct { float s[4]; } rvb_float3;                                              /* 16 B */
+typedef struct { float specular[8]; float diffuse[8]; } rvb_surface;                    /* 64 B */
+typedef struct { float volume[8]; float position[4]; float time; float pad_[3]; } rvb_impulse;     /* 64 B */
+typedef struct { float volume[8]; float time; float pad_[7]; } rvb_attenuated_impulse;  /* 64 B */
+typedef struct { float direction[4]; float coefficient; float pad_[3]; } rvb_speaker;   /* 32 B */
+
+/* One valid image-source contribution of one ray (what the reference keeps per work-item in
+ * image_source[i*10+slot] / image_source_index[i*10+slot], kernel.cpp:258-264), compacted. */
+typedef struct {
+    uint64_t ray;            /* global ray index (ray_offset of the trace call added) */
+    uint32_t slot;           /* 1..9 (slot 0, the direct path, is reported separately) */
+    uint32_t index;          /* triangle index + 1 (kernel.cpp:453) */
+    rvb_impulse impulse;
+} rvb_image_candidate;       /* 80 B */
+
+typedef struct rvb_ctx rvb_ctx;
+
+/* ---- life cycle: replaces ContextProvider / KernelLoader (rayverb.cpp:151-192) ------------- */
+int rvb_create(rvb_ctx ** out, int device, unsigned flags);
+void rvb_destroy(rvb_ctx * ctx);
+const char * rvb_last_error(const rvb_ctx * ctx);       /* ctx may be NULL after a failed rvb_create */
+int rvb_synchronize(rvb_ctx * ctx);                     /* wait for the context's stream */
+/* Name ("gfx950"), compute-unit count and HBM bytes of the bound device. */
+int rvb_device_info(rvb_ctx * ctx, char * arch, uint64_t arch_capacity, int * compute_units, uint64_t * hbm_bytes);
+
+/* ---- scene: replaces the geometry half of Raytracer::Raytracer (rayverb.cpp:242-293) --------
+ * Copies triangles / vertices / surfaces, builds the BVH on the host and uploads everything.
+ * Triangle and surface indices are validated (the reference never calls its own
+ * SceneData::valid(), rayverb.cpp:463-502; out-of-range indices are rejected here). */
+int rvb_set_scene(rvb_ctx * ctx,
+                  const rvb_triangle * triangles, uint64_t ntriangles,
+                  const rvb_float3 * vertices, uint64_t nvertices,
+                  const rvb_surface * surfaces, uint64_t nsurfaces);
+/* BVH statistics of the current scene (nodes, leaf triangles kept, tree depth). */
+int rvb_scene_info(rvb_ctx * ctx, uint64_t * nodes, uint64_t * kept_triangles, uint32_t * depth);
+
+/* ---- ray directions: replaces the per-group cl::copy of rayverb.cpp:593-598 ---------------- */
+int rvb_set_directions(rvb_ctx * ctx, const rvb_float3 * directions, uint64_t nrays);          /* host */
+int rvb_set_directions_device(rvb_ctx * ctx, const void * d_directions, uint64_t nrays);        /* device, borrowed */
+
+/* ---- trace: replaces Raytracer::raytrace (rayverb.cpp:538-685) + kernel raytrace
+ * (kernel.cpp:304-503).  Traces exactly nrays rays (all at once, no 4096-ray groups) for
+ * nreflections bounces; results stay in HBM.  Asynchronous on the context's stream.
+ * ray_offset is added to ray numbers reported by rvb_get_image_candidates (multi-GPU shards). */
+int rvb_trace(rvb_ctx * ctx, const float mic[3], const float source[3],
+              uint64_t nreflections, const float air_coefficient[8], uint64_t ray_offset);
+
+/* ---- raw results: replace getRawDiffuse / getRawImages (rayverb.cpp:687-714) ---------------- */
+int rvb_get_diffuse(rvb_ctx * ctx, rvb_impulse * out /* host [nrays*nreflections] */);
+/* Device address of the same array (valid until the next rvb_trace / rvb_destroy). */
+int rvb_diffuse_device(rvb_ctx * ctx, const void ** d_impulses, uint64_t * count);
+/* Direct-path impulse (slot 0; all-zero when the source is not visible from the microphone). */
+int rvb_get_direct(rvb_ctx * ctx, rvb_impulse * out);
+/* Valid image-source contributions of this context's rays, sorted by (ray, slot). */
+int rvb_get_image_candidates(rvb_ctx * ctx, rvb_image_candidate * out, uint64_t capacity, uint64_t * count);
+/* Host-only merge = the de-dup map of rayverb.cpp:654-676 followed by getRawImages
+ * (rayverb.cpp:692-706): first (lowest) ray wins per key, output in std::map key order.
+ * Candidates of several contexts (GPU shards) may be concatenated before the call. */
+int rvb_merge_images(const rvb_image_candidate * candidates, uint64_t ncandidates,
+                     const rvb_impulse * direct, int remove_direct,
+                     rvb_impulse * out, uint64_t capacity, uint64_t * count);
+
+/* ---- attenuation, materialised: replace SpeakerAttenuator::attenuate (rayverb.cpp:856-892 +
+ * kernel attenuate, kernel.cpp:505-535) and HrtfAttenuator::attenuate (rayverb.cpp:765-818 +
+ * kernel hrtf, kernel.cpp:537-625) for ONE channel.  Host in, host out.  Impulses whose volume
+ * is all-zero give {0, 0} (the reference leaves them uninitialised, quirk Q2). */
+int rvb_attenuate_speaker(rvb_ctx * ctx, const float mic[3], const rvb_impulse * in, uint64_t n,
+                          const rvb_speaker * speaker, rvb_attenuated_impulse * out);
+int rvb_attenuate_hrtf(rvb_ctx * ctx, const float mic[3], const rvb_impulse * in, uint64_t n,
+                       const float * table /* [360*180*8] for this ear */,
+                       const float facing[3], const float up[3], uint64_t channel,
+                       rvb_attenuated_impulse * out);
+
+/* ---- time binning, materialised: replaces flattenImpulses (rayverb.cpp:48-77) for one channel.
+ * Bit-exact with the reference's serial summation order.  out is [8][*nbins]. */
+int rvb_flatten(rvb_ctx * ctx, const rvb_attenuated_impulse * in, uint64_t n, float sample_rate,
+                float * out, uint64_t capacity_bins, uint64_t * nbins);
+
+/* ---- fused, device-resident IR generation (attenuate + predelay + bin without materialising
+ * AttenuatedImpulse): replaces the chain Attenuator::attenuate -> fixPredelay ->
+ * flattenImpulses of cmd/main.cpp:280-298 + rayverb.h:49-97 + rayverb.cpp:28-77.
+ *
+ * 1. rvb_ir_configure_*   choose the attenuation model and which impulses take part;
+ *                         extra image impulses (already merged) are uploaded here.
+ * 2. rvb_ir_time_range    min non-zero / max attenuated time over all channels of this context
+ *                         (the inputs of findPredelay and of MAX_SAMPLE); with several GPUs the
+ *                         caller all-reduces (min, max) before step 3.
+ * 3. rvb_ir_accumulate    adds this context's impulses into d_histogram [nchannels][8][nbins]
+ *                         (device memory, caller-zeroed, float).  mode RVB_IR_FAST uses float
+ *                         atomics (order-dependent in the last bits); RVB_IR_EXACT reproduces the
+ *                         reference's serial summation order bit for bit (single context only).
+ */
+enum { RVB_IR_DIFFUSE = 1, RVB_IR_IMAGES = 2, RVB_IR_ALL = 3 };   /* OutputMode, config.h:19-23 */
+enum { RVB_IR_FAST = 0, RVB_IR_EXACT = 1 };
+
+int rvb_ir_configure_speakers(rvb_ctx * ctx, const float mic[3], const rvb_speaker * speakers, uint64_t nspeakers,
+                              int which, const rvb_impulse * images, uint64_t nimages);
+int rvb_ir_configure_hrtf(rvb_ctx * ctx, const float mic[3], const float * table /* [2][360*180*8] */,
+                          const float facing[3], const float up[3],
+                          int which, const rvb_impulse * images, uint64_t nimages);
+int rvb_ir_time_range(rvb_ctx * ctx, float * min_nonzero_time, float * max_time);
+/* nbins for a given max time / predelay exactly as rayverb.cpp:57 computes MAX_SAMPLE. */
+uint64_t rvb_ir_bins(float max_time, float predelay, float sample_rate);
+int rvb_ir_accumulate(rvb_ctx * ctx, float predelay, float sample_rate, uint64_t nbins, int mode,
+                      void * d_histogram);
+/* Convenience for one GPU: steps 1-3 done, histogram copied to host memory [nchannels][8][*nbins]. */
+int rvb_ir_download(rvb_ctx * ctx, int trim_predelay, float sample_rate, int mode,
+                    float * out, uint64_t capacity_bins, uint64_t * nbins);
+
+/* ---- measurement hooks (bench.py) ------------------------------------------------------------
+ * Durations in milliseconds of the kernels of the last rvb_trace / rvb_ir_accumulate, taken with
+ * HIP events on the context's stream; names is a ';'-separated list matching ms[]. */
+int rvb_last_timings(rvb_ctx * ctx, char * names, uint64_t names_capacity, float * ms, uint64_t ms_capacity, uint64_t * count);
+/* Number of bounces actually executed by the last trace (escaped rays stop early). */
+int rvb_executed_bounces(rvb_ctx * ctx, uint64_t * bounces);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

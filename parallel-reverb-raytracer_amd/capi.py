@@ -1,0 +1,274 @@
+"""ctypes binding of include/rvb_capi.h (librvb_hip.so) for tests and bench.py.
+
+The method names follow the reference's host API for the path (reference rayverb/rayverb.h):
+`Raytracer.raytrace / getRawDiffuse / getRawImages / getAllRaw`, `SpeakerAttenuator.attenuate`,
+`HrtfAttenuator.attenuate`, `flattenImpulses`.  There is no CPU fallback: if the shared library is
+missing or no gfx950 device is usable this module raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from .dtypes import ATTENUATED, IMPULSE, SPEAKER, aligned_zeros
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librvb_hip.so")
+
+IMAGE_CANDIDATE = np.dtype([("ray", "<u8"), ("slot", "<u4"), ("index", "<u4"), ("impulse", IMPULSE)])
+assert IMAGE_CANDIDATE.itemsize == 80
+
+IR_DIFFUSE, IR_IMAGES, IR_ALL = 1, 2, 3
+IR_FAST, IR_EXACT = 0, 1
+
+# every symbol include/rvb_capi.h declares
+SYMBOLS = [
+    "rvb_create", "rvb_destroy", "rvb_last_error", "rvb_synchronize", "rvb_device_info",
+    "rvb_set_scene", "rvb_scene_info", "rvb_set_directions", "rvb_set_directions_device", "rvb_trace",
+    "rvb_get_diffuse", "rvb_diffuse_device", "rvb_get_direct", "rvb_get_image_candidates", "rvb_merge_images",
+    "rvb_attenuate_speaker", "rvb_attenuate_hrtf", "rvb_flatten",
+    "rvb_ir_configure_speakers", "rvb_ir_configure_hrtf", "rvb_ir_time_range", "rvb_ir_bins", "rvb_ir_accumulate",
+    "rvb_ir_download", "rvb_last_timings", "rvb_executed_bounces",
+]
+
+_vp = ctypes.c_void_p
+_u64 = ctypes.c_uint64
+_lib = None
+
+
+class RvbError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("rvb error %d: %s" % (code, message))
+        self.code = code
+
+
+def load_library():
+    """Loads librvb_hip.so (built by `make -C parallel-reverb-raytracer_amd`); raises if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("%s not built: run __graft_entry__.build() (no CPU fallback exists)" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        lib.rvb_last_error.restype = ctypes.c_char_p
+        lib.rvb_last_error.argtypes = [_vp]
+        lib.rvb_ir_bins.restype = _u64
+        lib.rvb_ir_bins.argtypes = [ctypes.c_float, ctypes.c_float, ctypes.c_float]
+        lib.rvb_destroy.restype = None
+        lib.rvb_destroy.argtypes = [_vp]
+        _lib = lib
+    return _lib
+
+
+def _f3(v):
+    return (ctypes.c_float * 3)(*[float(x) for x in v])
+
+
+def _f8(v):
+    return (ctypes.c_float * 8)(*[float(x) for x in v])
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_vp) if a is not None else None
+
+
+def make_speakers(directions, coefficients):
+    sp = aligned_zeros(len(coefficients), SPEAKER)
+    sp["direction"][:, :3] = np.asarray(directions, np.float32).reshape(-1, 3)
+    sp["coefficient"] = np.asarray(coefficients, np.float32)
+    return sp
+
+
+def merge_images(candidates, direct, remove_direct):
+    """Host de-dup of image-source candidates (reference rayverb.cpp:654-676 + :692-706)."""
+    lib = load_library()
+    cand = np.ascontiguousarray(candidates, dtype=IMAGE_CANDIDATE)
+    count = _u64(0)
+    d = np.ascontiguousarray(direct, dtype=IMPULSE) if direct is not None else None
+    rc = lib.rvb_merge_images(_ptr(cand), _u64(cand.shape[0]), _ptr(d), ctypes.c_int(int(remove_direct)), None, _u64(0),
+                              ctypes.byref(count))
+    if rc:
+        raise RvbError(rc, "rvb_merge_images")
+    out = np.zeros(count.value, dtype=IMPULSE)
+    rc = lib.rvb_merge_images(_ptr(cand), _u64(cand.shape[0]), _ptr(d), ctypes.c_int(int(remove_direct)), _ptr(out),
+                              _u64(out.shape[0]), ctypes.byref(count))
+    if rc:
+        raise RvbError(rc, "rvb_merge_images")
+    return out
+
+
+class Context:
+    """One GPU, one HIP stream (rvb_ctx)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        self.handle = _vp()
+        rc = self.lib.rvb_create(ctypes.byref(self.handle), ctypes.c_int(device), ctypes.c_uint(0))
+        if rc:
+            raise RvbError(rc, self.lib.rvb_last_error(None).decode())
+        self.nrays = 0
+        self.nreflections = 0
+        self.nchannels = 0
+        self._keep = []
+
+    def close(self):
+        if self.handle:
+            self.lib.rvb_destroy(self.handle)
+            self.handle = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise RvbError(rc, self.lib.rvb_last_error(self.handle).decode())
+
+    # ---- Raytracer ------------------------------------------------------------------------------
+    def set_scene(self, scene):
+        triangles, vertices, surfaces = scene
+        triangles, vertices, surfaces = (np.ascontiguousarray(x) for x in (triangles, vertices, surfaces))
+        self._check(self.lib.rvb_set_scene(self.handle, _ptr(triangles), _u64(triangles.shape[0]), _ptr(vertices),
+                                           _u64(vertices.shape[0]), _ptr(surfaces), _u64(surfaces.shape[0])))
+
+    def scene_info(self):
+        nodes, kept, depth = _u64(0), _u64(0), ctypes.c_uint32(0)
+        self._check(self.lib.rvb_scene_info(self.handle, ctypes.byref(nodes), ctypes.byref(kept), ctypes.byref(depth)))
+        return {"nodes": nodes.value, "kept_triangles": kept.value, "depth": depth.value}
+
+    def device_info(self):
+        arch = ctypes.create_string_buffer(64)
+        cus, hbm = ctypes.c_int(0), _u64(0)
+        self._check(self.lib.rvb_device_info(self.handle, arch, _u64(64), ctypes.byref(cus), ctypes.byref(hbm)))
+        return {"arch": arch.value.decode(), "compute_units": cus.value, "hbm_bytes": hbm.value}
+
+    def set_directions(self, directions):
+        d = np.ascontiguousarray(np.asarray(directions, np.float32).reshape(-1, 4))
+        self._check(self.lib.rvb_set_directions(self.handle, _ptr(d), _u64(d.shape[0])))
+        self.nrays = d.shape[0]
+
+    def set_directions_device(self, device_pointer, nrays):
+        self._check(self.lib.rvb_set_directions_device(self.handle, _vp(device_pointer), _u64(nrays)))
+        self.nrays = nrays
+
+    def trace(self, mic, source, nreflections, air, ray_offset=0):
+        self._check(self.lib.rvb_trace(self.handle, _f3(mic), _f3(source), _u64(nreflections), _f8(air), _u64(ray_offset)))
+        self.nreflections = int(nreflections)
+
+    def raytrace(self, mic, source, directions, nreflections, air):
+        """Raytracer::raytrace (reference rayverb.cpp:538-685)."""
+        self.set_directions(directions)
+        self.trace(mic, source, nreflections, air)
+
+    def synchronize(self):
+        self._check(self.lib.rvb_synchronize(self.handle))
+
+    def get_raw_diffuse(self):
+        out = np.zeros(self.nrays * self.nreflections, dtype=IMPULSE)
+        self._check(self.lib.rvb_get_diffuse(self.handle, _ptr(out)))
+        return out
+
+    def diffuse_device(self):
+        p, n = _vp(), _u64(0)
+        self._check(self.lib.rvb_diffuse_device(self.handle, ctypes.byref(p), ctypes.byref(n)))
+        return p.value, n.value
+
+    def get_direct(self):
+        out = np.zeros(1, dtype=IMPULSE)
+        self._check(self.lib.rvb_get_direct(self.handle, _ptr(out)))
+        return out
+
+    def get_image_candidates(self):
+        count = _u64(0)
+        self._check(self.lib.rvb_get_image_candidates(self.handle, None, _u64(0), ctypes.byref(count)))
+        out = np.zeros(count.value, dtype=IMAGE_CANDIDATE)
+        self._check(self.lib.rvb_get_image_candidates(self.handle, _ptr(out), _u64(out.shape[0]), ctypes.byref(count)))
+        return out
+
+    def get_raw_images(self, remove_direct):
+        """Raytracer::getRawImages (reference rayverb.cpp:692-706)."""
+        direct = self.get_direct() if self.nrays else None
+        return merge_images(self.get_image_candidates(), direct, remove_direct)
+
+    def get_all_raw(self, remove_direct):
+        return np.concatenate([self.get_raw_diffuse(), self.get_raw_images(remove_direct)])
+
+    def executed_bounces(self):
+        v = _u64(0)
+        self._check(self.lib.rvb_executed_bounces(self.handle, ctypes.byref(v)))
+        return v.value
+
+    def last_timings(self):
+        names = ctypes.create_string_buffer(1024)
+        ms = (ctypes.c_float * 32)()
+        count = _u64(0)
+        self._check(self.lib.rvb_last_timings(self.handle, names, _u64(1024), ms, _u64(32), ctypes.byref(count)))
+        keys = names.value.decode().split(";") if count.value else []
+        return [(k, float(ms[i])) for i, k in enumerate(keys)]
+
+    # ---- SpeakerAttenuator / HrtfAttenuator (materialised, one channel per call) --------------------
+    def attenuate_speaker(self, mic, impulses, direction, coefficient):
+        imp = np.ascontiguousarray(impulses, dtype=IMPULSE)
+        sp = make_speakers([direction], [coefficient])
+        out = np.zeros(imp.shape[0], dtype=ATTENUATED)
+        self._check(self.lib.rvb_attenuate_speaker(self.handle, _f3(mic), _ptr(imp), _u64(imp.shape[0]), _ptr(sp), _ptr(out)))
+        return out
+
+    def attenuate_hrtf(self, mic, impulses, table_channel, facing, up, channel):
+        imp = np.ascontiguousarray(impulses, dtype=IMPULSE)
+        table = np.ascontiguousarray(table_channel, dtype=np.float32).reshape(-1)
+        assert table.shape[0] == 360 * 180 * 8
+        out = np.zeros(imp.shape[0], dtype=ATTENUATED)
+        self._check(self.lib.rvb_attenuate_hrtf(self.handle, _f3(mic), _ptr(imp), _u64(imp.shape[0]), _ptr(table), _f3(facing),
+                                                _f3(up), _u64(channel), _ptr(out)))
+        return out
+
+    def flatten(self, attenuated, sample_rate):
+        """flattenImpulses for one channel (reference rayverb.cpp:48-77) -> [8][nbins]."""
+        a = np.ascontiguousarray(attenuated, dtype=ATTENUATED)
+        nbins = _u64(0)
+        self._check(self.lib.rvb_flatten(self.handle, _ptr(a), _u64(a.shape[0]), ctypes.c_float(sample_rate), None, _u64(0),
+                                         ctypes.byref(nbins)))
+        out = np.zeros((8, nbins.value), dtype=np.float32)
+        self._check(self.lib.rvb_flatten(self.handle, _ptr(a), _u64(a.shape[0]), ctypes.c_float(sample_rate), _ptr(out),
+                                         _u64(nbins.value), ctypes.byref(nbins)))
+        return out
+
+    # ---- fused impulse-response stage ------------------------------------------------------------------
+    def ir_configure_speakers(self, mic, directions, coefficients, which=IR_ALL, images=None):
+        sp = make_speakers(directions, coefficients)
+        img = np.ascontiguousarray(images, dtype=IMPULSE) if images is not None else np.zeros(0, dtype=IMPULSE)
+        self._check(self.lib.rvb_ir_configure_speakers(self.handle, _f3(mic), _ptr(sp), _u64(sp.shape[0]), ctypes.c_int(which),
+                                                       _ptr(img), _u64(img.shape[0])))
+        self.nchannels = sp.shape[0]
+
+    def ir_configure_hrtf(self, mic, table, facing, up, which=IR_ALL, images=None):
+        t = np.ascontiguousarray(table, dtype=np.float32).reshape(-1)
+        assert t.shape[0] == 2 * 360 * 180 * 8
+        img = np.ascontiguousarray(images, dtype=IMPULSE) if images is not None else np.zeros(0, dtype=IMPULSE)
+        self._check(self.lib.rvb_ir_configure_hrtf(self.handle, _f3(mic), _ptr(t), _f3(facing), _f3(up), ctypes.c_int(which),
+                                                   _ptr(img), _u64(img.shape[0])))
+        self.nchannels = 2
+
+    def ir_time_range(self):
+        lo, hi = ctypes.c_float(0), ctypes.c_float(0)
+        self._check(self.lib.rvb_ir_time_range(self.handle, ctypes.byref(lo), ctypes.byref(hi)))
+        return lo.value, hi.value
+
+    def ir_bins(self, max_time, predelay, sample_rate):
+        return int(self.lib.rvb_ir_bins(ctypes.c_float(max_time), ctypes.c_float(predelay), ctypes.c_float(sample_rate)))
+
+    def ir_accumulate(self, predelay, sample_rate, nbins, mode, device_histogram_pointer):
+        self._check(self.lib.rvb_ir_accumulate(self.handle, ctypes.c_float(predelay), ctypes.c_float(sample_rate), _u64(nbins),
+                                               ctypes.c_int(mode), _vp(device_histogram_pointer)))
+
+    def ir_download(self, trim_predelay, sample_rate, mode=IR_FAST):
+        """attenuate -> fixPredelay -> flattenImpulses (reference cmd/main.cpp:280-298) -> [nch][8][nbins]."""
+        nbins = _u64(0)
+        self._check(self.lib.rvb_ir_download(self.handle, ctypes.c_int(int(trim_predelay)), ctypes.c_float(sample_rate),
+                                             ctypes.c_int(mode), None, _u64(0), ctypes.byref(nbins)))
+        out = np.zeros((self.nchannels, 8, nbins.value), dtype=np.float32)
+        self._check(self.lib.rvb_ir_download(self.handle, ctypes.c_int(int(trim_predelay)), ctypes.c_float(sample_rate),
+                                             ctypes.c_int(mode), _ptr(out), _u64(nbins.value), ctypes.byref(nbins)))
+        return out

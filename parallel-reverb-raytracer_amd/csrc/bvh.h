@@ -1,0 +1,62 @@
+// bvh.h — acceleration structure of the trace kernels (new design: the reference has none and
+// scans all triangles per query, reference rayverb/kernel.cpp:167-192).
+//
+// The BVH only decides WHICH triangles get tested; every candidate is tested with the
+// reference's own Möller–Trumbore arithmetic (rvb_math.h mt_intersect) and the winner is chosen
+// by the reference's rule (smallest distance > EPSILON, ties to the lowest triangle index,
+// kernel.cpp:180-188), so a query returns what the brute-force scan returns.  Boxes are padded
+// and the cull test carries slack (see kPad / cull_slack in trace_kernels.hip) because the
+// float result of the triangle test can land slightly outside the true triangle / true distance.
+//
+// HBM layout (all arrays read-only during a trace, resident in L2 / Infinity Cache):
+//   nodes   : BvhNode[],   128 B, 4-wide, breadth-first (top levels contiguous), SoA boxes
+//   tris    : BvhTri[],     48 B, in leaf order: v0, e0, e1 (edges precomputed), original index
+//   shade   : TriShade[],   16 B, by ORIGINAL triangle index: unit normal + surface index
+//   verts9  : TriCorners[], 48 B, by ORIGINAL triangle index: the three vertices (image-source)
+#pragma once
+
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/rvb_capi.h"
+
+#define RVB_BVH_EMPTY 0xFFFFFFFFu
+#define RVB_BVH_LEAF 0x80000000u
+#define RVB_BVH_MAX_LEAF 4
+#define RVB_BVH_STACK 64            // per-lane traversal stack entries (LDS)
+
+struct BvhNode {                    // 128 B
+    float lox[4], loy[4], loz[4];
+    float hix[4], hiy[4], hiz[4];
+    uint32_t child[4];              // EMPTY | LEAF|(count-1)<<28|first | node index
+    uint32_t pad[4];
+};
+
+struct BvhTri {                     // 48 B
+    float v0[3];
+    float e0[3];
+    float e1[3];
+    uint32_t index;                 // original triangle index (tie-break + results)
+    uint32_t surface;
+    uint32_t pad;
+};
+
+struct TriShade { float n[3]; uint32_t surface; };     // 16 B
+struct TriCorners { float v[9]; float pad[3]; };       // 48 B
+
+struct BuiltScene {
+    std::vector<BvhNode> nodes;
+    std::vector<BvhTri> tris;
+    std::vector<TriShade> shade;
+    std::vector<TriCorners> corners;
+    uint32_t depth = 0;             // levels of 4-wide nodes
+    uint32_t stack_need = 0;        // worst-case traversal stack entries (<= RVB_BVH_STACK)
+    float pad = 0.0f;               // box padding actually used (metres)
+    float bounds_lo[3] = {0, 0, 0}, bounds_hi[3] = {0, 0, 0};
+};
+
+// Returns an empty string on success, else the error text.
+std::string rvb_build_scene(const rvb_triangle * triangles, uint64_t ntriangles,
+                            const rvb_float3 * vertices, uint64_t nvertices,
+                            uint64_t nsurfaces, BuiltScene & out);

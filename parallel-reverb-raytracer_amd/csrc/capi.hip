@@ -1,0 +1,748 @@
+// capi.hip — implementation of include/rvb_capi.h: context, HBM buffers, call order.
+// No compute happens here and nothing falls back to the CPU: every entry point that produces
+// results launches the HIP kernels of trace_kernels.hip / stream_kernels.hip.
+#include "../../include/rvb_capi.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void * p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap)
+            return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release() { if (p) (void) hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T * as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct Timing { std::string name; hipEvent_t start, stop; };
+
+}  // namespace
+
+struct rvb_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string error;
+    std::string arch;
+    int compute_units = 0;
+    uint64_t hbm_bytes = 0;
+
+    // scene
+    bool have_scene = false;
+    DevBuf nodes, tris, shade, corners, surfaces;
+    SceneDev scene;
+    uint64_t nnodes = 0, kept = 0;
+    uint32_t depth = 0;
+
+    // rays + trace results
+    DevBuf directions_own;
+    const float4 * directions = nullptr;
+    uint64_t nrays = 0;
+    bool traced = false;
+    uint64_t nreflections = 0;
+    float mic[3] = {0, 0, 0};
+    DevBuf impulses, early, candidates, small;       // small: [0] candidate count, [2..3] executed, [16..] direct, range
+    std::vector<Timing> timings;
+    std::vector<hipEvent_t> event_pool;
+    size_t events_used = 0;
+
+    // impulse-response stage
+    bool ir_configured = false;
+    AttenuationModel model;
+    int which = RVB_IR_ALL;
+    DevBuf images, hrtf_table, acc, keys_a, keys_b, vals_a, vals_b, sort_temp, scratch_in, scratch_out, hist;
+    uint64_t nimages = 0;
+
+    hipEvent_t next_event()
+    {
+        if (events_used == event_pool.size()) {
+            hipEvent_t e;
+            (void) hipEventCreate(&e);
+            event_pool.push_back(e);
+        }
+        return event_pool[events_used++];
+    }
+    void begin_timing(const char * name)
+    {
+        Timing t;
+        t.name = name;
+        t.start = next_event();
+        t.stop = next_event();
+        (void) hipEventRecord(t.start, stream);
+        timings.push_back(t);
+    }
+    void end_timing() { (void) hipEventRecord(timings.back().stop, stream); }
+    void reset_timings() { timings.clear(); events_used = 0; }
+};
+
+namespace {
+
+int fail(rvb_ctx * ctx, int code, const std::string & what)
+{
+    if (ctx) ctx->error = what; else g_create_error = what;
+    return code;
+}
+
+#define RVB_HIP(ctx, call)                                                                              \
+    do {                                                                                                \
+        hipError_t e_ = (call);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(ctx, RVB_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));           \
+    } while (0)
+
+#define RVB_BIND(ctx) RVB_HIP(ctx, hipSetDevice((ctx)->device))
+
+// small-buffer layout (bytes)
+const size_t kSmallCandidateCount = 0;
+const size_t kSmallExecuted = 8;
+const size_t kSmallRange = 16;      // two uint32
+const size_t kSmallMaxTime = 24;    // uint32
+const size_t kSmallDirect = 64;     // rvb_impulse
+const size_t kSmallBytes = 128;
+
+uint64_t bins_for(float max_time, float predelay, float sample_rate)
+{
+    const float t = max_time > predelay ? max_time - predelay : 0.0f;   // rayverb.h:89
+    return (uint64_t) (roundf(t * sample_rate) + 1);                    // rayverb.cpp:57
+}
+
+int key_bits_for(uint64_t nbins)
+{
+    int bits = 1;
+    while (bits < 32 && (1ull << bits) < nbins + 1)
+        ++bits;
+    return bits;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rvb_create(rvb_ctx ** out, int device, unsigned flags)
+{
+    (void) flags;
+    if (!out)
+        return fail(nullptr, RVB_ERR_INVALID, "rvb_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(nullptr, RVB_ERR_NO_DEVICE,
+                    std::string("rvb_create: no HIP device (") + (e != hipSuccess ? hipGetErrorString(e) : "count 0") +
+                    "); this library has no CPU path");
+    if (device < 0 || device >= count)
+        return fail(nullptr, RVB_ERR_INVALID, "rvb_create: device index out of range");
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess)
+        return fail(nullptr, RVB_ERR_NO_DEVICE, std::string("hipGetDeviceProperties: ") + hipGetErrorString(e));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, RVB_ERR_NO_DEVICE, std::string("rvb_create: kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+    rvb_ctx * ctx = new rvb_ctx();
+    ctx->device = device;
+    ctx->arch = prop.gcnArchName;
+    ctx->compute_units = prop.multiProcessorCount;
+    ctx->hbm_bytes = prop.totalGlobalMem;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = ctx->small.ensure(kSmallBytes)) != hipSuccess) {
+        std::string what = std::string("rvb_create: ") + hipGetErrorString(e);
+        delete ctx;
+        return fail(nullptr, RVB_ERR_HIP, what);
+    }
+    *out = ctx;
+    return RVB_OK;
+}
+
+void rvb_destroy(rvb_ctx * ctx)
+{
+    if (!ctx)
+        return;
+    (void) hipSetDevice(ctx->device);
+    if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
+    for (DevBuf * b : {&ctx->nodes, &ctx->tris, &ctx->shade, &ctx->corners, &ctx->surfaces, &ctx->directions_own, &ctx->impulses,
+                       &ctx->early, &ctx->candidates, &ctx->small, &ctx->images, &ctx->hrtf_table, &ctx->acc, &ctx->keys_a,
+                       &ctx->keys_b, &ctx->vals_a, &ctx->vals_b, &ctx->sort_temp, &ctx->scratch_in, &ctx->scratch_out, &ctx->hist})
+        b->release();
+    for (hipEvent_t e : ctx->event_pool) (void) hipEventDestroy(e);
+    if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char * rvb_last_error(const rvb_ctx * ctx)
+{
+    return ctx ? ctx->error.c_str() : g_create_error.c_str();
+}
+
+int rvb_synchronize(rvb_ctx * ctx)
+{
+    if (!ctx) return RVB_ERR_INVALID;
+    RVB_BIND(ctx);
+    RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RVB_OK;
+}
+
+int rvb_device_info(rvb_ctx * ctx, char * arch, uint64_t arch_capacity, int * compute_units, uint64_t * hbm_bytes)
+{
+    if (!ctx) return RVB_ERR_INVALID;
+    if (arch && arch_capacity) {
+        std::strncpy(arch, ctx->arch.c_str(), arch_capacity - 1);
+        arch[arch_capacity - 1] = 0;
+    }
+    if (compute_units) *compute_units = ctx->compute_units;
+    if (hbm_bytes) *hbm_bytes = ctx->hbm_bytes;
+    return RVB_OK;
+}
+
+int rvb_set_scene(rvb_ctx * ctx, const rvb_triangle * triangles, uint64_t ntriangles,
+                  const rvb_float3 * vertices, uint64_t nvertices,
+                  const rvb_surface * surfaces, uint64_t nsurfaces)
+{
+    if (!ctx) return RVB_ERR_INVALID;
+    if ((ntriangles && !triangles) || (nvertices && !vertices) || !surfaces || nsurfaces == 0)
+        return fail(ctx, RVB_ERR_INVALID, "rvb_set_scene: null input or no surfaces");
+    RVB_BIND(ctx);
+    BuiltScene built;
+    std::string err = rvb_build_scene(triangles, ntriangles, vertices, nvertices, nsurfaces, built);
+    if (!err.empty())
+        return fail(ctx, err.find("stack") != std::string::npos ? RVB_ERR_CAPACITY : RVB_ERR_INVALID, "rvb_set_scene: " + err);
+    RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_scene = false;
+    ctx->traced = false;
+    auto upload = [&](DevBuf & b, const void * src, size_t bytes) -> hipError_t {
+        hipError_t e = b.ensure(bytes);
+        if (e != hipSuccess || bytes == 0) return e;
+        return hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice);
+    };
+    RVB_HIP(ctx, upload(ctx->nodes, built.nodes.data(), built.nodes.size() * sizeof(BvhNode)));
+    RVB_HIP(ctx, upload(ctx->tris, built.tris.data(), built.tris.size() * sizeof(BvhTri)));
+    RVB_HIP(ctx, upload(ctx->shade, built.shade.data(), built.shade.size() * sizeof(TriShade)));
+    RVB_HIP(ctx, upload(ctx->corners, built.corners.data(), built.corners.size() * sizeof(TriCorners)));
+    RVB_HIP(ctx, upload(ctx->surfaces, surfaces, nsurfaces * sizeof(rvb_surface)));
+    ctx->scene.nodes = ctx->nodes.as<const BvhNode>();
+    ctx->scene.tris = ctx->tris.as<const BvhTri>();
+    ctx->scene.shade = ctx->shade.as<const TriShade>();
+    ctx->scene.corners = ctx->corners.as<const TriCorners>();
+    ctx->scene.surfaces = ctx->surfaces.as<const rvb_surface>();
+    // cull slack along the ray: the float distance of a triangle may differ from the exact one
+    ctx->scene.cull_abs = built.pad;
+    ctx->scene.cull_rel = 1e-4f;
+    ctx->nnodes = built.nodes.size();
+    ctx->kept = built.tris.size();
+    ctx->depth = built.depth;
+    ctx->have_scene = true;
+    return RVB_OK;
+}
+
+int rvb_scene_info(rvb_ctx * ctx, uint64_t * nodes, uint64_t * kept_triangles, uint32_t * depth)
+{
+    if (!ctx) return RVB_ERR_INVALID;
+    if (!ctx->have_scene) return fail(ctx, RVB_ERR_STATE, "rvb_scene_info: no scene");
+    if (nodes) *nodes = ctx->nnodes;
+    if (kept_triangles) *kept_triangles = ctx->kept;
+    if (depth) *depth = ctx->depth;
+    return RVB_OK;
+}
+
+int rvb_set_directions(rvb_ctx * ctx, const rvb_float3 * directions, uint64_t nrays)
+{
+    if (!ctx) return RVB_ERR_INVALID;
+    if (nrays && !directions) return fail(ctx, RVB_ERR_INVALID, "rvb_set_directions: null directions");
+    RVB_BIND(ctx);
+    RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RVB_HIP(ctx, ctx->directions_own.ensure(nrays * sizeof(rvb_float3)));
+    if (nrays)
+        RVB_HIP(ctx, hipMemcpy(ctx->directions_own.p, directions, nrays * sizeof(rvb_float3), hipMemcpyHostToDevice));
+    ctx->directions = ctx->directions_own.as<const float4>();
+    ctx->nrays = nrays;
+    ctx->traced = false;
+    return RVB_OK;
+}
+
+int rvb_set_directions_device(rvb_ctx * ctx, const void * d_directions, uint64_t nrays)
+{
+    if (!ctx) return RVB_ERR_INVALID;
+    if (nrays && !d_directions) return fail(ctx, RVB_ERR_INVALID, "rvb_set_directions_device: null directions");
+    ctx->directions = reinterpret_cast<const float4 *>(d_directions);
+    ctx->nrays = nrays;
+    ctx->traced = false;
+    return RVB_OK;
+}
+
+int rvb_trace(rvb_ctx * ctx, const float mic[3], const float source[3], uint64_t nreflections,
+              const float air_coefficient[8], uint64_t ray_offset)
+{
+    if (!ctx) return RVB_ERR_INVALID;
+    if (!mic || !source || !air_coefficient) return fail(ctx, RVB_ERR_INVALID, "rvb_trace: null argument");
+    if (!ctx->have_scene) return fail(ctx, RVB_ERR_STATE, "rvb_trace: rvb_set_scene has not been called");
+    if (!ctx->directions && ctx->nrays) return fail(ctx, RVB_ERR_STATE, "rvb_trace: no directions");
+    if (nreflections >= (1ull << 31) || ctx->nrays * 9 >= (1ull << 32))
+        return fail(ctx, RVB_ERR_CAPACITY, "rvb_trace: too many reflections or rays for one context");
+    RVB_BIND(ctx);
+    const uint64_t nrays = ctx->nrays;
+    const size_t imp_bytes = (size_t) nrays * nreflections * sizeof(rvb_impulse);
+    const size_t early_bytes = (size_t) nrays * 9 * sizeof(uint32_t);
+    RVB_HIP(ctx, ctx->impulses.ensure(imp_bytes));
+    RVB_HIP(ctx, ctx->early.ensure(early_bytes));
+    RVB_HIP(ctx, ctx->candidates.ensure((size_t) nrays * 9 * sizeof(rvb_image_candidate)));
+
+    // reference rayverb.cpp:600-616: outputs start zero-filled
+    if (imp_bytes) RVB_HIP(ctx, hipMemsetAsync(ctx->impulses.p, 0, imp_bytes, ctx->stream));
+    if (early_bytes) RVB_HIP(ctx, hipMemsetAsync(ctx->early.p, 0xFF, early_bytes, ctx->stream));
+    RVB_HIP(ctx, hipMemsetAsync(ctx->small.p, 0, kSmallBytes, ctx->stream));
+
+    TraceArgs a;
+    a.scene = ctx->scene;
+    a.directions = ctx->directions;
+    a.impulses = ctx->impulses.as<rvb_impulse>();
+    a.early = ctx->early.as<uint32_t>();
+    a.candidates = ctx->candidates.as<rvb_image_candidate>();
+    a.candidate_count = reinterpret_cast<uint32_t *>(ctx->small.as<char>() + kSmallCandidateCount);
+    a.direct = reinterpret_cast<rvb_impulse *>(ctx->small.as<char>() + kSmallDirect);
+    a.executed = reinterpret_cast<unsigned long long *>(ctx->small.as<char>() + kSmallExecuted);
+    a.nrays = nrays;
+    a.nreflections = (uint32_t) nreflections;
+    a.ray_offset = ray_offset;
+    for (int i = 0; i < 3; ++i) { a.mic[i] = mic[i]; a.source[i] = source[i]; ctx->mic[i] = mic[i]; }
+    for (int i = 0; i < 8; ++i) a.air[i] = air_coefficient[i];
+
+    ctx->reset_timings();
+    ctx->begin_timing("path_kernel");
+    rvb_launch_path(a, ctx->stream);
+    ctx->end_timing();
+    ctx->begin_timing("image_kernel");
+    rvb_launch_images(a, ctx->stream);
+    ctx->end_timing();
+    ctx->begin_timing("shadow_kernel");
+    rvb_launch_shadow(a, ctx->stream);
+    ctx->end_timing();
+    RVB_HIP(ctx, hipGetLastError());
+    ctx->nreflections = nreflections;
+    ctx->traced = true;
+    ctx->ir_configured = false;
+    return RVB_OK;
+}
+
+int rvb_get_diffuse(rvb_ctx * ctx, rvb_impulse * out)
+{
+    if (!ctx) return RVB_ERR_INVALID;
+    if (!ctx->traced) return fail(ctx, RVB_ERR_STATE, "rvb_get_diffuse: nothing traced");
+    RVB_BIND(ctx);
+    RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t bytes = (size_t) ctx->nrays * ctx->nreflections * sizeof(rvb_impulse);
+    if (bytes) {
+        if (!out) return fail(ctx, RVB_ERR_INVALID, "rvb_get_diffuse: null output");
+        RVB_HIP(ctx, hipMemcpy(out, ctx->impulses.p, bytes, hipMemcpyDeviceToHost));
+    }
+    return RVB_OK;
+}
+
+int rvb_diffuse_device(rvb_ctx * ctx, const void ** d_impulses, uint64_t * count)
+{
+    if (!ctx) return RVB_ERR_INVALID;
+    if (!ctx->traced) return fail(ctx, RVB_ERR_STATE, "rvb_diffuse_device: nothing traced");
+    if (d_impulses) *d_impulses = ctx->impulses.p;
+    if (count) *count = ctx->nrays * ctx->nreflections;
+    return RVB_OK;
+}
+
+int rvb_get_direct(rvb_ctx * ctx, rvb_impulse * out)
+{
+    if (!ctx || !out) return RVB_ERR_INVALID;
+    if (!ctx->traced) return fail(ctx, RVB_ERR_STATE, "rvb_get_direct: nothing traced");
+    RVB_BIND(ctx);
+    RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RVB_HIP(ctx, hipMemcpy(out, ctx->small.as<char>() + kSmallDirect, sizeof(rvb_impulse), hipMemcpyDeviceToHost));
+    return RVB_OK;
+}
+
+int rvb_get_image_candidates(rvb_ctx * ctx, rvb_image_candidate * out, uint64_t capacity, uint64_t * count)
+{
+    if (!ctx || !count) return RVB_ERR_INVALID;
+    if (!ctx->traced) return fail(ctx, RVB_ERR_STATE, "rvb_get_image_candidates: nothing traced");
+    RVB_BIND(ctx);
+    RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    uint32_t n = 0;
+    RVB_HIP(ctx, hipMemcpy(&n, ctx->small.as<char>() + kSmallCandidateCount, sizeof(n), hipMemcpyDeviceToHost));
+    *count = n;
+    if (!out)
+        return RVB_OK;                       // size query
+    if (capacity < n)
+        return fail(ctx, RVB_ERR_CAPACITY, "rvb_get_image_candidates: capacity too small");
+    if (n) {
+        RVB_HIP(ctx, hipMemcpy(out, ctx->candidates.p, (size_t) n * sizeof(rvb_image_candidate), hipMemcpyDeviceToHost));
+        std::sort(out, out + n, [](const rvb_image_candidate & x, const rvb_image_candidate & y) {
+            return x.ray != y.ray ? x.ray < y.ray : x.slot < y.slot;
+        });
+    }
+    return RVB_OK;
+}
+
+int rvb_merge_images(const rvb_image_candidate * candidates, uint64_t ncandidates,
+                     const rvb_impulse * direct, int remove_direct,
+                     rvb_impulse * out, uint64_t capacity, uint64_t * count)
+{
+    if (!count || (ncandidates && !candidates))
+        return RVB_ERR_INVALID;
+    // reference rayverb.cpp:654-676: for each ray j and k = 1..10 the key is the first k entries of
+    // the ray's index row; inserted if absent when k == 1 or the last entry is non-zero.  Entries
+    // are zero except where a candidate exists, so rows are rebuilt from the candidates alone.
+    std::vector<rvb_image_candidate> sorted(candidates, candidates + ncandidates);
+    std::sort(sorted.begin(), sorted.end(), [](const rvb_image_candidate & x, const rvb_image_candidate & y) {
+        return x.ray != y.ray ? x.ray < y.ray : x.slot < y.slot;
+    });
+    std::map<std::vector<unsigned long>, rvb_impulse> tally;
+    if (direct)
+        tally[std::vector<unsigned long>(1, 0)] = *direct;      // k == 1: key {0} from ray 0
+    size_t i = 0;
+    while (i < sorted.size()) {
+        size_t j = i;
+        unsigned long row[RVB_NUM_IMAGE_SOURCE] = {0};
+        while (j < sorted.size() && sorted[j].ray == sorted[i].ray) {
+            if (sorted[j].slot == 0 || sorted[j].slot >= RVB_NUM_IMAGE_SOURCE)
+                return RVB_ERR_INVALID;
+            row[sorted[j].slot] = sorted[j].index;
+            ++j;
+        }
+        for (size_t c = i; c < j; ++c) {
+            std::vector<unsigned long> key(row, row + sorted[c].slot + 1);
+            if (tally.find(key) == tally.end())
+                tally[key] = sorted[c].impulse;
+        }
+        i = j;
+    }
+    if (remove_direct)
+        tally.erase(std::vector<unsigned long>(1, 0));          // rayverb.cpp:695-696
+    *count = tally.size();
+    if (!out)
+        return RVB_OK;
+    if (capacity < tally.size())
+        return RVB_ERR_CAPACITY;
+    size_t w = 0;
+    for (const auto & kv : tally)
+        out[w++] = kv.second;
+    return RVB_OK;
+}
+
+// ---- materialised attenuation / flatten ---------------------------------------------------------
+
+static int upload_hrtf_table(rvb_ctx * ctx, const float * table, int ears)
+{
+    // device layout [ear][360*180 + 1][8]; the extra row is the zero padding behind quirk Q5
+    const size_t row = 360 * 180;
+    std::vector<float> padded((size_t) 2 * (row + 1) * 8, 0.0f);
+    for (int e = 0; e < ears; ++e)
+        std::memcpy(padded.data() + (size_t) e * (row + 1) * 8, table + (size_t) e * row * 8, row * 8 * sizeof(float));
+    RVB_HIP(ctx, ctx->hrtf_table.ensure(padded.size() * sizeof(float)));
+    RVB_HIP(ctx, hipMemcpy(ctx->hrtf_table.p, padded.data(), padded.size() * sizeof(float), hipMemcpyHostToDevice));
+    return RVB_OK;
+}
+
+static int run_attenuate(rvb_ctx * ctx, const AttenuationModel & m, uint32_t channel, const rvb_impulse * in, uint64_t n,
+                         rvb_attenuated_impulse * out)
+{
+    if (n == 0) return RVB_OK;
+    if (!in || !out) return fail(ctx, RVB_ERR_INVALID, "attenuate: null buffer");
+    RVB_HIP(ctx, ctx->scratch_in.ensure(n * sizeof(rvb_impulse)));
+    RVB_HIP(ctx, ctx->scratch_out.ensure(n * sizeof(rvb_attenuated_impulse)));
+    RVB_HIP(ctx, hipMemcpyAsync(ctx->scratch_in.p, in, n * sizeof(rvb_impulse), hipMemcpyHostToDevice, ctx->stream));
+    ctx->reset_timings();
+    ctx->begin_timing("attenuate_kernel");
+    rvb_launch_attenuate(m, channel, ctx->scratch_in.as<rvb_impulse>(), n, ctx->scratch_out.as<rvb_attenuated_impulse>(), ctx->stream);
+    ctx->end_timing();
+    RVB_HIP(ctx, hipGetLastError());
+    RVB_HIP(ctx, hipMemcpyAsync(out, ctx->scratch_out.p, n * sizeof(rvb_attenuated_impulse), hipMemcpyDeviceToHost, ctx->stream));
+    RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RVB_OK;
+}
+
+int rvb_attenuate_speaker(rvb_ctx * ctx, const float mic[3], const rvb_impulse * in, uint64_t n,
+                          const rvb_speaker * speaker, rvb_attenuated_impulse * out)
+{
+    if (!ctx) return RVB_ERR_INVALID;
+    if (!mic || !speaker) return fail(ctx, RVB_ERR_INVALID, "rvb_attenuate_speaker: null argument");
+    RVB_BIND(ctx);
+    AttenuationModel m;
+    m.hrtf = 0;
+    m.nchannels = 1;
+    for (int i = 0; i < 3; ++i) { m.mic[i] = mic[i]; m.speaker_dir[0][i] = speaker->direction[i]; }
+    m.speaker_coeff[0] = speaker->coefficient;
+    return run_attenuate(ctx, m, 0, in, n, out);
+}
+
+int rvb_attenuate_hrtf(rvb_ctx * ctx, const float mic[3], const rvb_impulse * in, uint64_t n,
+                       const float * table, const float facing[3], const float up[3], uint64_t channel,
+                       rvb_attenuated_impulse * out)
+{
+    if (!ctx) return RVB_ERR_INVALID;
+    if (!mic || !table || !facing || !up || channel > 1) return fail(ctx, RVB_ERR_INVALID, "rvb_attenuate_hrtf: bad argument");
+    RVB_BIND(ctx);
+    RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // the table handed in is this ear's; park it in the ear's slot of the device image
+    std::vector<float> both((size_t) 2 * 360 * 180 * 8, 0.0f);
+    std::memcpy(both.data() + (size_t) channel * 360 * 180 * 8, table, (size_t) 360 * 180 * 8 * sizeof(float));
+    int rc = upload_hrtf_table(ctx, both.data(), 2);
+    if (rc != RVB_OK) return rc;
+    AttenuationModel m;
+    m.hrtf = 1;
+    m.nchannels = 2;
+    m.hrtf_table = ctx->hrtf_table.as<const float>();
+    for (int i = 0; i < 3; ++i) { m.mic[i] = mic[i]; m.facing[i] = facing[i]; m.up[i] = up[i]; }
+    ctx->ir_configured = false;
+    return run_attenuate(ctx, m, (uint32_t) channel, in, n, out);
+}
+
+static int ensure_sort_buffers(rvb_ctx * ctx, uint64_t n)
+{
+    RVB_HIP(ctx, ctx->keys_a.ensure(n * 4));
+    RVB_HIP(ctx, ctx->keys_b.ensure(n * 4));
+    RVB_HIP(ctx, ctx->vals_a.ensure(n * 4));
+    RVB_HIP(ctx, ctx->vals_b.ensure(n * 4));
+    RVB_HIP(ctx, ctx->sort_temp.ensure(rvb_sort_temp_bytes(n)));
+    return RVB_OK;
+}
+
+int rvb_flatten(rvb_ctx * ctx, const rvb_attenuated_impulse * in, uint64_t n, float sample_rate,
+                float * out, uint64_t capacity_bins, uint64_t * nbins)
+{
+    if (!ctx || !nbins) return RVB_ERR_INVALID;
+    if (n && !in) return fail(ctx, RVB_ERR_INVALID, "rvb_flatten: null input");
+    if (n >= (1ull << 32)) return fail(ctx, RVB_ERR_CAPACITY, "rvb_flatten: too many impulses");
+    RVB_BIND(ctx);
+    RVB_HIP(ctx, ctx->scratch_in.ensure(n * sizeof(rvb_attenuated_impulse)));
+    int rc = ensure_sort_buffers(ctx, n);
+    if (rc != RVB_OK) return rc;
+    uint32_t * max_bits = reinterpret_cast<uint32_t *>(ctx->small.as<char>() + kSmallMaxTime);
+    RVB_HIP(ctx, hipMemsetAsync(max_bits, 0, 4, ctx->stream));
+    if (n) RVB_HIP(ctx, hipMemcpyAsync(ctx->scratch_in.p, in, n * sizeof(rvb_attenuated_impulse), hipMemcpyHostToDevice, ctx->stream));
+    rvb_launch_flat_keys(ctx->scratch_in.as<rvb_attenuated_impulse>(), n, sample_rate, ctx->keys_a.as<uint32_t>(),
+                         ctx->vals_a.as<uint32_t>(), max_bits, ctx->stream);
+    uint32_t bits = 0;
+    RVB_HIP(ctx, hipMemcpyAsync(&bits, max_bits, 4, hipMemcpyDeviceToHost, ctx->stream));
+    RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    float max_time;
+    std::memcpy(&max_time, &bits, 4);
+    const uint64_t bins = bins_for(max_time, 0.0f, sample_rate);
+    *nbins = bins;
+    if (!out)
+        return RVB_OK;
+    if (capacity_bins < bins)
+        return fail(ctx, RVB_ERR_CAPACITY, "rvb_flatten: capacity_bins too small");
+    RVB_HIP(ctx, ctx->hist.ensure(bins * 8 * sizeof(float)));
+    rvb_sort_pairs(ctx->sort_temp.p, ctx->sort_temp.cap, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(),
+                   ctx->vals_a.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), n, key_bits_for(bins), ctx->stream);
+    rvb_launch_flat_ordered_sum(ctx->scratch_in.as<rvb_attenuated_impulse>(), ctx->keys_b.as<uint32_t>(), ctx->vals_b.as<uint32_t>(),
+                                n, bins, ctx->hist.as<float>(), ctx->stream);
+    RVB_HIP(ctx, hipGetLastError());
+    RVB_HIP(ctx, hipMemcpyAsync(out, ctx->hist.p, bins * 8 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RVB_OK;
+}
+
+// ---- fused impulse-response stage ----------------------------------------------------------------
+
+static int configure_common(rvb_ctx * ctx, int which, const rvb_impulse * images, uint64_t nimages)
+{
+    if (!ctx->traced) return fail(ctx, RVB_ERR_STATE, "rvb_ir_configure: nothing traced");
+    if (which < 1 || which > 3) return fail(ctx, RVB_ERR_INVALID, "rvb_ir_configure: which must be 1..3");
+    if (nimages && !images) return fail(ctx, RVB_ERR_INVALID, "rvb_ir_configure: null images");
+    RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RVB_HIP(ctx, ctx->images.ensure(nimages * sizeof(rvb_impulse)));
+    if (nimages) RVB_HIP(ctx, hipMemcpy(ctx->images.p, images, nimages * sizeof(rvb_impulse), hipMemcpyHostToDevice));
+    ctx->nimages = nimages;
+    ctx->which = which;
+    ctx->ir_configured = true;
+    return RVB_OK;
+}
+
+int rvb_ir_configure_speakers(rvb_ctx * ctx, const float mic[3], const rvb_speaker * speakers, uint64_t nspeakers,
+                              int which, const rvb_impulse * images, uint64_t nimages)
+{
+    if (!ctx) return RVB_ERR_INVALID;
+    if (!mic || !speakers || nspeakers == 0 || nspeakers > 8)
+        return fail(ctx, RVB_ERR_INVALID, "rvb_ir_configure_speakers: 1..8 speakers required");
+    RVB_BIND(ctx);
+    AttenuationModel m;
+    m.hrtf = 0;
+    m.nchannels = (uint32_t) nspeakers;
+    for (int i = 0; i < 3; ++i) m.mic[i] = mic[i];
+    for (uint64_t s = 0; s < nspeakers; ++s) {
+        for (int i = 0; i < 3; ++i) m.speaker_dir[s][i] = speakers[s].direction[i];
+        m.speaker_coeff[s] = speakers[s].coefficient;
+    }
+    ctx->model = m;
+    return configure_common(ctx, which, images, nimages);
+}
+
+int rvb_ir_configure_hrtf(rvb_ctx * ctx, const float mic[3], const float * table, const float facing[3], const float up[3],
+                          int which, const rvb_impulse * images, uint64_t nimages)
+{
+    if (!ctx) return RVB_ERR_INVALID;
+    if (!mic || !table || !facing || !up) return fail(ctx, RVB_ERR_INVALID, "rvb_ir_configure_hrtf: null argument");
+    RVB_BIND(ctx);
+    RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = upload_hrtf_table(ctx, table, 2);
+    if (rc != RVB_OK) return rc;
+    AttenuationModel m;
+    m.hrtf = 1;
+    m.nchannels = 2;
+    m.hrtf_table = ctx->hrtf_table.as<const float>();
+    for (int i = 0; i < 3; ++i) { m.mic[i] = mic[i]; m.facing[i] = facing[i]; m.up[i] = up[i]; }
+    ctx->model = m;
+    return configure_common(ctx, which, images, nimages);
+}
+
+int rvb_ir_time_range(rvb_ctx * ctx, float * min_nonzero_time, float * max_time)
+{
+    if (!ctx) return RVB_ERR_INVALID;
+    if (!ctx->ir_configured) return fail(ctx, RVB_ERR_STATE, "rvb_ir_time_range: rvb_ir_configure_* first");
+    RVB_BIND(ctx);
+    uint32_t * range = reinterpret_cast<uint32_t *>(ctx->small.as<char>() + kSmallRange);
+    RVB_HIP(ctx, hipMemsetAsync(range, 0xFF, 4, ctx->stream));
+    RVB_HIP(ctx, hipMemsetAsync(range + 1, 0, 4, ctx->stream));
+    ctx->reset_timings();
+    ctx->begin_timing("time_range_kernel");
+    if (ctx->which & RVB_IR_DIFFUSE)
+        rvb_launch_time_range(ctx->model, ctx->impulses.as<rvb_impulse>(), ctx->nrays * ctx->nreflections, range, ctx->stream);
+    if (ctx->which & RVB_IR_IMAGES)
+        rvb_launch_time_range(ctx->model, ctx->images.as<rvb_impulse>(), ctx->nimages, range, ctx->stream);
+    ctx->end_timing();
+    RVB_HIP(ctx, hipGetLastError());
+    uint32_t got[2];
+    RVB_HIP(ctx, hipMemcpyAsync(got, range, sizeof(got), hipMemcpyDeviceToHost, ctx->stream));
+    RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    float lo = 0.0f, hi;
+    if (got[0] != 0xFFFFFFFFu) std::memcpy(&lo, &got[0], 4);
+    std::memcpy(&hi, &got[1], 4);
+    if (min_nonzero_time) *min_nonzero_time = lo;
+    if (max_time) *max_time = hi;
+    return RVB_OK;
+}
+
+uint64_t rvb_ir_bins(float max_time, float predelay, float sample_rate)
+{
+    return bins_for(max_time, predelay, sample_rate);
+}
+
+int rvb_ir_accumulate(rvb_ctx * ctx, float predelay, float sample_rate, uint64_t nbins, int mode, void * d_histogram)
+{
+    if (!ctx) return RVB_ERR_INVALID;
+    if (!ctx->ir_configured) return fail(ctx, RVB_ERR_STATE, "rvb_ir_accumulate: rvb_ir_configure_* first");
+    if (!d_histogram || nbins == 0) return fail(ctx, RVB_ERR_INVALID, "rvb_ir_accumulate: null histogram or no bins");
+    RVB_BIND(ctx);
+    const AttenuationModel & m = ctx->model;
+    const uint64_t ndiffuse = (ctx->which & RVB_IR_DIFFUSE) ? ctx->nrays * ctx->nreflections : 0;
+    const uint64_t nimages = (ctx->which & RVB_IR_IMAGES) ? ctx->nimages : 0;
+    float * hist = reinterpret_cast<float *>(d_histogram);
+    ctx->reset_timings();
+    if (mode == RVB_IR_FAST) {
+        const size_t acc_bytes = (size_t) nbins * m.nchannels * 8 * sizeof(float);
+        RVB_HIP(ctx, ctx->acc.ensure(acc_bytes));
+        RVB_HIP(ctx, hipMemsetAsync(ctx->acc.p, 0, acc_bytes, ctx->stream));
+        ctx->begin_timing("histogram_fast_kernel");
+        rvb_launch_histogram_fast(m, ctx->impulses.as<rvb_impulse>(), ndiffuse, predelay, sample_rate, nbins, ctx->acc.as<float>(), ctx->stream);
+        rvb_launch_histogram_fast(m, ctx->images.as<rvb_impulse>(), nimages, predelay, sample_rate, nbins, ctx->acc.as<float>(), ctx->stream);
+        ctx->end_timing();
+        ctx->begin_timing("histogram_transpose_kernel");
+        rvb_launch_histogram_transpose(ctx->acc.as<float>(), hist, m.nchannels, nbins, ctx->stream);
+        ctx->end_timing();
+    } else if (mode == RVB_IR_EXACT) {
+        const uint64_t n = ndiffuse + nimages;
+        if (n >= (1ull << 32)) return fail(ctx, RVB_ERR_CAPACITY, "rvb_ir_accumulate: too many impulses for exact mode");
+        int rc = ensure_sort_buffers(ctx, n);
+        if (rc != RVB_OK) return rc;
+        ctx->begin_timing("exact_mode");
+        for (uint32_t ch = 0; ch < m.nchannels; ++ch) {
+            rvb_launch_bin_keys(m, ch, ctx->impulses.as<rvb_impulse>(), ndiffuse, 0, predelay, sample_rate,
+                                ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), ctx->stream);
+            rvb_launch_bin_keys(m, ch, ctx->images.as<rvb_impulse>(), nimages, ndiffuse, predelay, sample_rate,
+                                ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), ctx->stream);
+            rvb_sort_pairs(ctx->sort_temp.p, ctx->sort_temp.cap, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(),
+                           ctx->vals_a.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), n, 32, ctx->stream);
+            rvb_launch_ordered_sum(m, ch, ctx->impulses.as<rvb_impulse>(), ndiffuse, ctx->images.as<rvb_impulse>(), nimages,
+                                   ctx->keys_b.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), n, nbins,
+                                   hist + (size_t) ch * 8 * nbins, ctx->stream);
+        }
+        ctx->end_timing();
+    } else {
+        return fail(ctx, RVB_ERR_INVALID, "rvb_ir_accumulate: unknown mode");
+    }
+    RVB_HIP(ctx, hipGetLastError());
+    return RVB_OK;
+}
+
+int rvb_ir_download(rvb_ctx * ctx, int trim_predelay, float sample_rate, int mode,
+                    float * out, uint64_t capacity_bins, uint64_t * nbins)
+{
+    if (!ctx || !nbins) return RVB_ERR_INVALID;
+    float lo = 0.0f, hi = 0.0f;
+    int rc = rvb_ir_time_range(ctx, &lo, &hi);
+    if (rc != RVB_OK) return rc;
+    const float predelay = trim_predelay ? lo : 0.0f;
+    const uint64_t bins = bins_for(hi, predelay, sample_rate);
+    *nbins = bins;
+    if (!out)
+        return RVB_OK;
+    if (capacity_bins < bins)
+        return fail(ctx, RVB_ERR_CAPACITY, "rvb_ir_download: capacity_bins too small");
+    const size_t bytes = (size_t) bins * ctx->model.nchannels * 8 * sizeof(float);
+    RVB_HIP(ctx, ctx->hist.ensure(bytes));
+    RVB_HIP(ctx, hipMemsetAsync(ctx->hist.p, 0, bytes, ctx->stream));
+    rc = rvb_ir_accumulate(ctx, predelay, sample_rate, bins, mode, ctx->hist.p);
+    if (rc != RVB_OK) return rc;
+    RVB_HIP(ctx, hipMemcpyAsync(out, ctx->hist.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RVB_OK;
+}
+
+int rvb_last_timings(rvb_ctx * ctx, char * names, uint64_t names_capacity, float * ms, uint64_t ms_capacity, uint64_t * count)
+{
+    if (!ctx || !count) return RVB_ERR_INVALID;
+    RVB_BIND(ctx);
+    RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::string joined;
+    uint64_t n = 0;
+    for (const Timing & t : ctx->timings) {
+        float v = 0.0f;
+        RVB_HIP(ctx, hipEventElapsedTime(&v, t.start, t.stop));
+        if (ms && n < ms_capacity) ms[n] = v;
+        if (!joined.empty()) joined += ';';
+        joined += t.name;
+        ++n;
+    }
+    *count = n;
+    if (names && names_capacity) {
+        std::strncpy(names, joined.c_str(), names_capacity - 1);
+        names[names_capacity - 1] = 0;
+    }
+    return RVB_OK;
+}
+
+int rvb_executed_bounces(rvb_ctx * ctx, uint64_t * bounces)
+{
+    if (!ctx || !bounces) return RVB_ERR_INVALID;
+    if (!ctx->traced) return fail(ctx, RVB_ERR_STATE, "rvb_executed_bounces: nothing traced");
+    RVB_BIND(ctx);
+    RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned long long v = 0;
+    RVB_HIP(ctx, hipMemcpy(&v, ctx->small.as<char>() + kSmallExecuted, sizeof(v), hipMemcpyDeviceToHost));
+    *bounces = v;
+    return RVB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,83 @@
+// kernels.h — launch interface between the C-ABI (capi.hip) and the HIP kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rvb_capi.h"
+#include "bvh.h"
+
+struct SceneDev {                       // device pointers of the current scene
+    const BvhNode * nodes = nullptr;
+    const BvhTri * tris = nullptr;
+    const TriShade * shade = nullptr;
+    const TriCorners * corners = nullptr;
+    const rvb_surface * surfaces = nullptr;
+    float cull_abs = 0.0f;              // slack added to the running closest distance when culling
+    float cull_rel = 0.0f;
+};
+
+struct TraceArgs {
+    SceneDev scene;
+    const float4 * directions;          // [nrays]
+    rvb_impulse * impulses;             // [nrays * nreflections]
+    uint32_t * early;                   // [nrays * 9] triangle hit at bounce 0..8, 0xFFFFFFFF = none
+    rvb_image_candidate * candidates;   // [nrays * 9] capacity
+    uint32_t * candidate_count;
+    rvb_impulse * direct;               // slot 0
+    unsigned long long * executed;      // bounces executed
+    uint64_t nrays;
+    uint32_t nreflections;
+    uint64_t ray_offset;
+    float mic[3];
+    float source[3];
+    float air[8];
+};
+
+// Phase A: one lane per ray, the sequential closest-hit / reflect chain (kernel.cpp:359-375,
+// :459-461, :478, :492-501).  Leaves a work record per bounce in impulses[].
+void rvb_launch_path(const TraceArgs & a, hipStream_t s);
+// Phase C: one lane per (ray, bounce < 9): image-source validation (kernel.cpp:379-457) + slot 0.
+void rvb_launch_images(const TraceArgs & a, hipStream_t s);
+// Phase B: one lane per (ray, bounce): diffuse shadow ray to the microphone and the final
+// Impulse (kernel.cpp:463-490).  Overwrites the work records.
+void rvb_launch_shadow(const TraceArgs & a, hipStream_t s);
+
+// ---- streaming kernels (stream_kernels.hip) ---------------------------------------------------
+struct AttenuationModel {
+    int hrtf = 0;                       // 0: speakers, 1: hrtf
+    uint32_t nchannels = 0;             // speakers: <= 8; hrtf: 2
+    float mic[3] = {0, 0, 0};
+    float speaker_dir[8][3] = {};       // normalised on device exactly as kernel.cpp:511 does
+    float speaker_coeff[8] = {};
+    const float * hrtf_table = nullptr; // device [2][360*180+1][8]
+    float facing[3] = {0, 0, 0}, up[3] = {0, 0, 0};
+};
+
+// kernel attenuate / hrtf for one channel, materialised (kernel.cpp:515-535, :586-625)
+void rvb_launch_attenuate(const AttenuationModel & m, uint32_t channel, const rvb_impulse * in, uint64_t n,
+                          rvb_attenuated_impulse * out, hipStream_t s);
+// min non-zero / max attenuated time over all channels -> range[0], range[1] (uint bits of floats;
+// caller initialises to 0xFFFFFFFF / 0)
+void rvb_launch_time_range(const AttenuationModel & m, const rvb_impulse * in, uint64_t n, uint32_t * range, hipStream_t s);
+// fused attenuate + predelay + bin with float atomics into the image acc[nbins][nchannels][8]
+void rvb_launch_histogram_fast(const AttenuationModel & m, const rvb_impulse * in, uint64_t n, float predelay,
+                               float sample_rate, uint64_t nbins, float * acc, hipStream_t s);
+// acc[bin][channel][band] -> hist[channel][band][bin] (added to what is there)
+void rvb_launch_histogram_transpose(const float * acc, float * hist, uint32_t nchannels, uint64_t nbins, hipStream_t s);
+// exact mode helpers: per-impulse bin keys, then the ordered per-bin summation
+void rvb_launch_bin_keys(const AttenuationModel & m, uint32_t channel, const rvb_impulse * in, uint64_t n, uint64_t index_base,
+                         float predelay, float sample_rate, uint32_t * keys, uint32_t * values, hipStream_t s);
+void rvb_launch_ordered_sum(const AttenuationModel & m, uint32_t channel, const rvb_impulse * diffuse, uint64_t ndiffuse,
+                            const rvb_impulse * images, uint64_t nimages,
+                            const uint32_t * sorted_keys, const uint32_t * sorted_values, uint64_t n,
+                            uint64_t nbins, float * hist_channel, hipStream_t s);
+// flattenImpulses of already attenuated impulses (rayverb.cpp:48-77): keys + ordered sum
+void rvb_launch_flat_keys(const rvb_attenuated_impulse * in, uint64_t n, float sample_rate, uint32_t * keys, uint32_t * values,
+                          uint32_t * max_time_bits, hipStream_t s);
+void rvb_launch_flat_ordered_sum(const rvb_attenuated_impulse * in, const uint32_t * sorted_keys, const uint32_t * sorted_values,
+                                 uint64_t n, uint64_t nbins, float * out, hipStream_t s);
+// stable sort of (key, value) pairs by key (device radix sort); temp storage managed by the caller
+size_t rvb_sort_temp_bytes(uint64_t n);
+void rvb_sort_pairs(void * temp, size_t temp_bytes, const uint32_t * keys_in, uint32_t * keys_out,
+                    const uint32_t * values_in, uint32_t * values_out, uint64_t n, int key_bits, hipStream_t s);

@@ -1,0 +1,421 @@
+// stream_kernels.hip — the per-impulse streaming stages: microphone / HRTF attenuation
+// (reference rayverb/kernel.cpp:505-625, kernels `attenuate` and `hrtf`), predelay
+// (rayverb/rayverb.h:49-97) and time binning (rayverb/rayverb.cpp:48-77, flattenImpulses).
+//
+// These are the HBM-bound kernels of the path: 64 B in (+ 64 B out when materialised) per
+// impulse.  Impulses are 64-byte records, so loads/stores are laid out so that one wave
+// instruction always covers a contiguous span:
+//   * materialised attenuate: 4 lanes per impulse, 16 B per lane  (1 KiB per wave instruction);
+//   * fused attenuate+bin   : 16 lanes per impulse, 4 B per lane, so that the 8 band volumes sit
+//     one per lane and one wave-wide float-atomic instruction adds 4 impulses x (2 channels x
+//     8 bands) = 4 x 64 contiguous bytes into the [bin][channel][band] accumulation image
+//     (memory-side atomics are paid per 64-byte request — MI355X_MICROARCH "Global float atomics").
+#include <cstring>
+#include <string.h>
+
+#include "kernels.h"
+#include "rvb_math.h"
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#define WAVE 64
+
+namespace {
+
+struct ModelDev {
+    int hrtf;
+    uint32_t nchannels;
+    v3 mic;
+    v3 sdir[8];             // speaker directions, already normalised (kernel.cpp:511)
+    float coeff[8];
+    const float * table;    // [2][360*180+1][8]
+    v3 pointing, up;
+    v3 ear[2];              // kernel.cpp:599-603
+};
+
+// reference kernel.cpp:537-549
+__host__ __device__ __forceinline__ v3 transform3(v3 pointing, v3 up, v3 d)
+{
+    v3 x = normalize3(cross3(up, pointing));
+    v3 y = cross3(pointing, x);
+    v3 z = pointing;
+    return mk3(dot3(x, d), dot3(y, d), dot3(z, d));
+}
+
+ModelDev make_model(const AttenuationModel & m)
+{
+    ModelDev d;
+    d.hrtf = m.hrtf;
+    d.nchannels = m.nchannels;
+    d.mic = mk3(m.mic[0], m.mic[1], m.mic[2]);
+    for (int i = 0; i < 8; ++i) {
+        d.sdir[i] = normalize3(mk3(m.speaker_dir[i][0], m.speaker_dir[i][1], m.speaker_dir[i][2]));
+        d.coeff[i] = m.speaker_coeff[i];
+    }
+    d.table = m.hrtf_table;
+    d.pointing = mk3(m.facing[0], m.facing[1], m.facing[2]);
+    d.up = mk3(m.up[0], m.up[1], m.up[2]);
+    const float width = 0.1f;                                   // kernel.cpp:597
+    d.ear[0] = transform3(d.pointing, d.up, mk3(-width, 0.0f, 0.0f)) + d.mic;
+    d.ear[1] = transform3(d.pointing, d.up, mk3(width, 0.0f, 0.0f)) + d.mic;
+    return d;
+}
+
+__device__ __forceinline__ float atan2_cr(float y, float x) { return (float) atan2((double) y, (double) x); }
+
+// reference kernel.cpp:505-513: gain of one speaker for an impulse at `pos`
+__device__ __forceinline__ float speaker_gain(const ModelDev & m, uint32_t ch, v3 pos)
+{
+    const v3 direction = normalize3(pos - m.mic);               // getDirection, kernel.cpp:528
+    return (1 - m.coeff[ch]) + m.coeff[ch] * dot3(normalize3(direction), m.sdir[ch]);
+}
+
+// reference kernel.cpp:563-584: table row selected for an impulse at `pos` (same for both ears)
+__device__ __forceinline__ int64_t hrtf_row(const ModelDev & m, v3 pos)
+{
+    const v3 t = transform3(m.pointing, m.up, normalize3(pos - m.mic));
+    const float az = atan2_cr(t.x, t.z);
+    const float el = atan2_cr(t.y, sqrtf(t.x * t.x + t.z * t.z));
+    int64_t a = (int64_t) (az * 57.295779513082320877f + 180);
+    a %= 360;
+    int64_t e = (int64_t) (el * 57.295779513082320877f);
+    e = 90 - e;
+    return a * 180 + e;     // e == 180 runs into the next azimuth row (quirk Q5); row 360*180 is zero padding
+}
+
+// reference kernel.cpp:616-622: arrival-time shift of one ear
+__device__ __forceinline__ float hrtf_time(const ModelDev & m, uint32_t ch, v3 pos, float time)
+{
+    const float dist0 = length3(pos - m.mic);
+    const float dist1 = length3(pos - m.ear[ch]);
+    const float diff = dist1 - dist0;
+    return time + diff * seconds_per_meter();
+}
+
+__device__ __forceinline__ float attenuated_time(const ModelDev & m, uint32_t ch, v3 pos, float time)
+{
+    return m.hrtf ? hrtf_time(m, ch, pos, time) : time;
+}
+
+// rayverb.h:89 fixPredelay, then rayverb.cpp:69 SAMPLE = round(time * samplerate)
+__device__ __forceinline__ uint32_t time_bin(float time, float predelay, float sample_rate)
+{
+    const float t = time > predelay ? time - predelay : 0.0f;
+    return (uint32_t) roundf(t * sample_rate);
+}
+
+// ---- materialised attenuation: 4 lanes per impulse -------------------------------------------
+__global__ __launch_bounds__(256) void attenuate_kernel(ModelDev m, uint32_t ch, const float4 * __restrict__ in,
+                                                        float4 * __restrict__ out, uint64_t n)
+{
+    const uint32_t q = threadIdx.x & 3u;
+    const uint64_t nchunks = n * 4;
+    for (uint64_t c = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; c < ((nchunks + 63) & ~63ull);
+         c += (uint64_t) gridDim.x * blockDim.x) {
+        const bool live = c < nchunks;
+        float4 v = live ? in[c] : make_float4(0, 0, 0, 0);
+        // chunk 2 = position, chunk 3 = time; quad lanes 0/1 hold the volumes
+        const int base = (int) (threadIdx.x & 63u & ~3u);
+        const float px = __shfl(v.x, base + 2), py = __shfl(v.y, base + 2), pz = __shfl(v.z, base + 2);
+        const float time = __shfl(v.x, base + 3);
+        const bool nz_local = q < 2 && (v.x != 0.0f || v.y != 0.0f || v.z != 0.0f || v.w != 0.0f);
+        const unsigned long long mask = __ballot(nz_local);
+        const bool nonzero = ((mask >> base) & 3ull) != 0;      // kernel.cpp:524 / :607 any(volume != 0)
+        float4 o = make_float4(0, 0, 0, 0);
+        if (nonzero) {
+            const v3 pos = mk3(px, py, pz);
+            if (!m.hrtf) {
+                const float g = speaker_gain(m, ch, pos);
+                if (q < 2) o = make_float4(v.x * g, v.y * g, v.z * g, v.w * g);
+                else if (q == 2) o.x = time;
+            } else {
+                const int64_t row = hrtf_row(m, pos);
+                if (q < 2) {
+                    const float4 t = reinterpret_cast<const float4 *>(m.table + ((uint64_t) ch * (360 * 180 + 1) + (uint64_t) row) * 8)[q];
+                    o = make_float4(v.x * t.x, v.y * t.y, v.z * t.z, v.w * t.w);
+                } else if (q == 2) {
+                    o.x = hrtf_time(m, ch, pos, time);
+                }
+            }
+        }
+        if (live) out[c] = o;
+    }
+}
+
+// ---- 16 lanes per impulse: lane f of a group holds float f of the record ----------------------
+//   f 0..7 volume, 8..10 position, 12 time
+struct Group16 {
+    float mine;       // this lane's float
+    v3 pos;
+    float time;
+    bool nonzero;
+};
+
+__device__ __forceinline__ Group16 load_group16(const float * __restrict__ in, uint64_t word, uint64_t nwords)
+{
+    Group16 g;
+    const uint32_t lane = threadIdx.x & 63u;
+    const int base = (int) (lane & ~15u);
+    g.mine = word < nwords ? in[word] : 0.0f;
+    g.pos = mk3(__shfl(g.mine, base + 8), __shfl(g.mine, base + 9), __shfl(g.mine, base + 10));
+    g.time = __shfl(g.mine, base + 12);
+    const unsigned long long mask = __ballot((lane & 15u) < 8u && g.mine != 0.0f);
+    g.nonzero = ((mask >> base) & 0xFFull) != 0;
+    return g;
+}
+
+__global__ __launch_bounds__(256) void time_range_kernel(ModelDev m, const float * __restrict__ in, uint64_t n, uint32_t * range)
+{
+    const uint64_t nwords = n * 16;
+    float tmin = __builtin_inff(), tmax = 0.0f;
+    for (uint64_t w = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; w < ((nwords + 63) & ~63ull);
+         w += (uint64_t) gridDim.x * blockDim.x) {
+        const Group16 g = load_group16(in, w, nwords);
+        if (!g.nonzero)
+            continue;           // attenuated impulse is {0, 0}: no part in findPredelay / maxtime
+        const uint32_t nch = m.hrtf ? 2u : 1u;   // speaker channels all keep the input time
+        for (uint32_t ch = 0; ch < nch; ++ch) {
+            const float t = attenuated_time(m, ch, g.pos, g.time);
+            if (t != 0.0f) tmin = fminf(tmin, t);
+            tmax = fmaxf(tmax, t);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        tmin = fminf(tmin, __shfl_xor(tmin, off));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, off));
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        if (tmin != __builtin_inff()) atomicMin(range + 0, __float_as_uint(tmin));
+        atomicMax(range + 1, __float_as_uint(tmax));
+    }
+}
+
+// accumulation image: acc[bin][channel][band], float atomics
+__global__ __launch_bounds__(256) void histogram_fast_kernel(ModelDev m, const float * __restrict__ in, uint64_t n,
+                                                             float predelay, float sample_rate, uint64_t nbins,
+                                                             float * __restrict__ acc)
+{
+    const uint64_t nwords = n * 16;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t f = lane & 15u;
+    const uint32_t band = f & 7u;
+    for (uint64_t w = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; w < ((nwords + 63) & ~63ull);
+         w += (uint64_t) gridDim.x * blockDim.x) {
+        const Group16 g = load_group16(in, w, nwords);
+        // lanes 8..15 of the group take the band volumes of lanes 0..7: second channel of a pair
+        const float vol = __shfl(g.mine, (int) ((lane & ~15u) + band));
+        if (!g.nonzero)
+            continue;
+        int64_t row = 0;
+        if (m.hrtf) row = hrtf_row(m, g.pos);
+        for (uint32_t pair = 0; pair < m.nchannels; pair += 2) {
+            const uint32_t ch = pair + (f >> 3);
+            if (ch >= m.nchannels)
+                continue;
+            float gain;
+            if (m.hrtf) gain = m.table[((uint64_t) ch * (360 * 180 + 1) + (uint64_t) row) * 8 + band];
+            else gain = speaker_gain(m, ch, g.pos);
+            const float t = attenuated_time(m, ch, g.pos, g.time);
+            const uint64_t bin = time_bin(t, predelay, sample_rate);
+            if (bin < nbins)
+                atomicAdd(acc + (bin * m.nchannels + ch) * 8 + band, vol * gain);
+        }
+    }
+}
+
+// acc[bin][ch][band] -> out[ch][band][bin] (+=, so that several shards / image passes can add up)
+__global__ __launch_bounds__(256) void histogram_transpose_kernel(const float * __restrict__ acc, float * __restrict__ out,
+                                                                  uint32_t nchannels, uint64_t nbins)
+{
+    const uint64_t total = nbins * nchannels * 8;
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t) gridDim.x * blockDim.x) {
+        const uint64_t bin = i % nbins;
+        const uint64_t cb = i / nbins;          // ch * 8 + band
+        out[i] += acc[bin * nchannels * 8 + cb];
+    }
+}
+
+// ---- exact mode -------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bin_keys_kernel(ModelDev m, uint32_t ch, const rvb_impulse * __restrict__ in, uint64_t n,
+                                                       uint64_t index_base, float predelay, float sample_rate,
+                                                       uint32_t * __restrict__ keys, uint32_t * __restrict__ values)
+{
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+        const float4 * r = reinterpret_cast<const float4 *>(in + i);
+        const float4 v0 = r[0], v1 = r[1], p = r[2];
+        const float time = r[3].x;
+        const bool nonzero = v0.x != 0.0f || v0.y != 0.0f || v0.z != 0.0f || v0.w != 0.0f
+                          || v1.x != 0.0f || v1.y != 0.0f || v1.z != 0.0f || v1.w != 0.0f;
+        float t = 0.0f;                       // {0, 0} for zero-volume impulses (quirk Q2) -> bin 0
+        if (nonzero) t = attenuated_time(m, ch, mk3(p.x, p.y, p.z), time);
+        keys[index_base + i] = time_bin(t, predelay, sample_rate);
+        values[index_base + i] = (uint32_t) (index_base + i);
+    }
+}
+
+__device__ __forceinline__ uint64_t lower_bound_u32(const uint32_t * a, uint64_t n, uint32_t key)
+{
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (a[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// One lane per bin: add the bin's impulses in impulse order (the order of rayverb.cpp:67-74).
+__global__ __launch_bounds__(64) void ordered_sum_kernel(ModelDev m, uint32_t ch, const rvb_impulse * __restrict__ diffuse, uint64_t ndiffuse,
+                                                         const rvb_impulse * __restrict__ images,
+                                                         const uint32_t * __restrict__ keys, const uint32_t * __restrict__ values,
+                                                         uint64_t n, uint64_t nbins, float * __restrict__ hist)
+{
+    const uint64_t bin = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (bin >= nbins)
+        return;
+    const uint64_t lo = lower_bound_u32(keys, n, (uint32_t) bin);
+    float sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint64_t k = lo; k < n && keys[k] == (uint32_t) bin; ++k) {
+        const uint64_t idx = values[k];
+        const rvb_impulse * imp = idx < ndiffuse ? diffuse + idx : images + (idx - ndiffuse);
+        const float4 * r = reinterpret_cast<const float4 *>(imp);
+        const float4 v0 = r[0], v1 = r[1], p = r[2];
+        const float vol[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        bool nonzero = false;
+        for (int b = 0; b < 8; ++b) nonzero = nonzero || vol[b] != 0.0f;
+        if (!nonzero)
+            continue;                         // adds +0 in the reference: no effect on the sums
+        const v3 pos = mk3(p.x, p.y, p.z);
+        if (m.hrtf) {
+            const float * t = m.table + ((uint64_t) ch * (360 * 180 + 1) + (uint64_t) hrtf_row(m, pos)) * 8;
+            for (int b = 0; b < 8; ++b) sum[b] += vol[b] * t[b];
+        } else {
+            const float g = speaker_gain(m, ch, pos);
+            for (int b = 0; b < 8; ++b) sum[b] += vol[b] * g;
+        }
+    }
+    for (int b = 0; b < 8; ++b)
+        hist[(uint64_t) b * nbins + bin] = sum[b];
+}
+
+__global__ __launch_bounds__(256) void flat_keys_kernel(const rvb_attenuated_impulse * __restrict__ in, uint64_t n, float sample_rate,
+                                                        uint32_t * __restrict__ keys, uint32_t * __restrict__ values,
+                                                        uint32_t * max_time_bits)
+{
+    float tmax = 0.0f;
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+        const float t = in[i].time;
+        tmax = fmaxf(tmax, t);
+        keys[i] = (uint32_t) roundf(t * sample_rate);
+        values[i] = (uint32_t) i;
+    }
+    for (int off = 32; off > 0; off >>= 1)
+        tmax = fmaxf(tmax, __shfl_xor(tmax, off));
+    if ((threadIdx.x & 63u) == 0)
+        atomicMax(max_time_bits, __float_as_uint(tmax));
+}
+
+__global__ __launch_bounds__(64) void flat_ordered_sum_kernel(const rvb_attenuated_impulse * __restrict__ in,
+                                                              const uint32_t * __restrict__ keys, const uint32_t * __restrict__ values,
+                                                              uint64_t n, uint64_t nbins, float * __restrict__ out)
+{
+    const uint64_t bin = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (bin >= nbins)
+        return;
+    const uint64_t lo = lower_bound_u32(keys, n, (uint32_t) bin);
+    float sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint64_t k = lo; k < n && keys[k] == (uint32_t) bin; ++k) {
+        const float4 * r = reinterpret_cast<const float4 *>(in + values[k]);
+        const float4 v0 = r[0], v1 = r[1];
+        sum[0] += v0.x; sum[1] += v0.y; sum[2] += v0.z; sum[3] += v0.w;
+        sum[4] += v1.x; sum[5] += v1.y; sum[6] += v1.z; sum[7] += v1.w;
+    }
+    for (int b = 0; b < 8; ++b)
+        out[(uint64_t) b * nbins + bin] = sum[b];
+}
+
+unsigned stream_blocks(uint64_t items, unsigned per_block)
+{
+    uint64_t blocks = (items + per_block - 1) / per_block;
+    if (blocks > 256u * 8u) blocks = 256u * 8u;       // 8 workgroups per CU, grid-stride the rest
+    return (unsigned) (blocks ? blocks : 1);
+}
+
+}  // namespace
+
+void rvb_launch_attenuate(const AttenuationModel & m, uint32_t channel, const rvb_impulse * in, uint64_t n,
+                          rvb_attenuated_impulse * out, hipStream_t s)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(attenuate_kernel, dim3(stream_blocks(n * 4, 256)), dim3(256), 0, s, make_model(m), channel,
+                       reinterpret_cast<const float4 *>(in), reinterpret_cast<float4 *>(out), n);
+}
+
+void rvb_launch_time_range(const AttenuationModel & m, const rvb_impulse * in, uint64_t n, uint32_t * range, hipStream_t s)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(time_range_kernel, dim3(stream_blocks(n * 16, 256)), dim3(256), 0, s, make_model(m),
+                       reinterpret_cast<const float *>(in), n, range);
+}
+
+void rvb_launch_histogram_fast(const AttenuationModel & m, const rvb_impulse * in, uint64_t n, float predelay,
+                               float sample_rate, uint64_t nbins, float * acc, hipStream_t s)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(histogram_fast_kernel, dim3(stream_blocks(n * 16, 256)), dim3(256), 0, s, make_model(m),
+                       reinterpret_cast<const float *>(in), n, predelay, sample_rate, nbins, acc);
+}
+
+void rvb_launch_histogram_transpose(const float * acc, float * out, uint32_t nchannels, uint64_t nbins, hipStream_t s)
+{
+    hipLaunchKernelGGL(histogram_transpose_kernel, dim3(stream_blocks(nbins * nchannels * 8, 256)), dim3(256), 0, s,
+                       acc, out, nchannels, nbins);
+}
+
+void rvb_launch_bin_keys(const AttenuationModel & m, uint32_t channel, const rvb_impulse * in, uint64_t n, uint64_t index_base,
+                         float predelay, float sample_rate, uint32_t * keys, uint32_t * values, hipStream_t s)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(bin_keys_kernel, dim3(stream_blocks(n, 256)), dim3(256), 0, s, make_model(m), channel, in, n,
+                       index_base, predelay, sample_rate, keys, values);
+}
+
+void rvb_launch_ordered_sum(const AttenuationModel & m, uint32_t channel, const rvb_impulse * diffuse, uint64_t ndiffuse,
+                            const rvb_impulse * images, uint64_t nimages,
+                            const uint32_t * sorted_keys, const uint32_t * sorted_values, uint64_t n,
+                            uint64_t nbins, float * hist_channel, hipStream_t s)
+{
+    (void) nimages;
+    if (nbins == 0) return;
+    hipLaunchKernelGGL(ordered_sum_kernel, dim3((unsigned) ((nbins + 63) / 64)), dim3(64), 0, s, make_model(m), channel,
+                       diffuse, ndiffuse, images, sorted_keys, sorted_values, n, nbins, hist_channel);
+}
+
+void rvb_launch_flat_keys(const rvb_attenuated_impulse * in, uint64_t n, float sample_rate, uint32_t * keys, uint32_t * values,
+                          uint32_t * max_time_bits, hipStream_t s)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(flat_keys_kernel, dim3(stream_blocks(n, 256)), dim3(256), 0, s, in, n, sample_rate, keys, values, max_time_bits);
+}
+
+void rvb_launch_flat_ordered_sum(const rvb_attenuated_impulse * in, const uint32_t * sorted_keys, const uint32_t * sorted_values,
+                                 uint64_t n, uint64_t nbins, float * out, hipStream_t s)
+{
+    if (nbins == 0) return;
+    hipLaunchKernelGGL(flat_ordered_sum_kernel, dim3((unsigned) ((nbins + 63) / 64)), dim3(64), 0, s, in, sorted_keys,
+                       sorted_values, n, nbins, out);
+}
+
+size_t rvb_sort_temp_bytes(uint64_t n)
+{
+    size_t bytes = 0;
+    (void) rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t *) nullptr, (uint32_t *) nullptr,
+                              (const uint32_t *) nullptr, (uint32_t *) nullptr, (size_t) n, 0, 32, (hipStream_t) 0);
+    return bytes;
+}
+
+void rvb_sort_pairs(void * temp, size_t temp_bytes, const uint32_t * keys_in, uint32_t * keys_out,
+                    const uint32_t * values_in, uint32_t * values_out, uint64_t n, int key_bits, hipStream_t s)
+{
+    if (n == 0) return;
+    (void) rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, values_in, values_out, (size_t) n, 0, (unsigned) key_bits, s);
+}

@@ -1,0 +1,233 @@
+"""GPU parity tests: the HIP path, called through the C-ABI, against the golden vectors of the
+reference's own kernels and against the CPU oracle on seeded inputs.
+
+Bars (BASELINE.json north_star: 1e-5 relative per band-bin; tighter here where the arithmetic allows):
+  * positions, times, triangle indices, image-source keys, bin indices: bit-exact;
+  * volumes: bit-exact (pow is evaluated in binary64 and rounded once on both sides — a mismatch of
+    1 ULP is possible in principle with probability ~1e-8 per value and would fail loudly here);
+  * exact-mode histograms: bit-exact with the reference's serial summation;
+  * fast-mode (float atomics) histograms: |diff| <= 1e-5 * |ref| + n_bin * 2^-23 * sum|terms| per band-bin.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden_impulses, golden_scene, load_golden
+from parallel_reverb_raytracer_amd import dtypes, scenes
+from parallel_reverb_raytracer_amd.dtypes import AIR_COEFFICIENTS, IMPULSE, NUM_IMAGE_SOURCE
+
+pytestmark = pytest.mark.gpu
+
+TRACE_CASES = ["trace_large_square", "trace_echo_tunnel", "trace_random_pillars", "trace_vault"]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from parallel_reverb_raytracer_amd import capi
+    c = capi.Context(0)          # raises when librvb_hip.so or the GPU is missing: no fallback
+    yield c
+    c.close()
+
+
+def assert_impulses_equal(got, want, what=""):
+    assert got.shape == want.shape, what
+    assert np.array_equal(got["position"][:, :3], want["position"][:, :3]), what + " positions"
+    assert np.array_equal(got["time"], want["time"]), what + " times"
+    assert np.array_equal(got["volume"], want["volume"]), what + " volumes"
+
+
+@pytest.mark.parametrize("name", TRACE_CASES)
+def test_trace_matches_reference_kernel_golden(ctx, oracle, name):
+    g = load_golden(name)
+    nrefl = int(g["nreflections"])
+    ctx.set_scene(golden_scene(g))
+    ctx.raytrace(g["mic"], g["source"], g["directions"], nrefl, g["air"])
+    got = ctx.get_raw_diffuse()
+    assert np.array_equal(got["position"][:, :3], g["impulse_position"])
+    assert np.array_equal(got["time"], g["impulse_time"])
+    assert np.array_equal(got["volume"], g["impulse_volume"])
+    assert not got["pad"].any() and not got["position"][:, 3].any()
+    # image sources: the reference's per-ray slots -> its de-dup map (restated in the oracle) vs ours
+    nrays = g["directions"].shape[0]
+    image = np.zeros(nrays * NUM_IMAGE_SOURCE, dtype=IMPULSE)
+    image["volume"], image["time"] = g["image_volume"], g["image_time"]
+    image["position"][:, :3] = g["image_position"]
+    for remove_direct in (False, True):
+        want = oracle.collect_images(image, g["image_index"], remove_direct)
+        assert_impulses_equal(ctx.get_raw_images(remove_direct), want, "images")
+    # every valid per-ray slot individually
+    cand = ctx.get_image_candidates()
+    idx = g["image_index"].reshape(nrays, NUM_IMAGE_SOURCE)
+    rays, slots = np.nonzero(idx[:, 1:])
+    assert cand.shape[0] == rays.shape[0]
+    assert np.array_equal(cand["ray"], rays) and np.array_equal(cand["slot"], slots + 1)
+    assert np.array_equal(cand["index"], idx[rays, slots + 1])
+    assert_impulses_equal(cand["impulse"], image.reshape(nrays, NUM_IMAGE_SOURCE)[rays, slots + 1], "candidates")
+    assert_impulses_equal(ctx.get_direct(), image[:1], "direct")
+
+
+def test_reference_gtest_known_answers(ctx):
+    """reference tests/raytrace_tests.h:35-47 through the HIP path."""
+    g = load_golden("trace_large_square")
+    ctx.set_scene(golden_scene(g))
+    ctx.raytrace(g["mic"], g["source"], g["directions"], 128, g["air"])
+    pos = ctx.get_raw_diffuse()["position"].reshape(-1, 128, 4)[:, :, :3]
+    bounce0 = [(0, 2, -27), (0, 2, 27), (0, 0, 2), (0, 27, 2), (-25, 2, 2), (25, 2, 2)]
+    bounce1 = [(0, 0, 0), (0, 0, 0), (0, 27, 2), (0, 0, 2), (-25, 2, -2), (25, 2, -2)]
+    for r in range(6):
+        np.testing.assert_array_almost_equal_nulp(pos[r, 0], np.float32(bounce0[r]), nulp=4)
+        np.testing.assert_array_almost_equal_nulp(pos[r, 1] + np.float32(64), np.float32(bounce1[r]) + np.float32(64), nulp=4)
+
+
+SEEDED = [
+    ("room_768", lambda: (scenes.rotated_square_room(n=8), (0.5, 2.0, 0.25), (-3.0, 4.0, 2.0)), 512, 24),
+    ("cathedral_3k", lambda: (scenes.cathedral(3000)[0], (14.0, 1.6, -0.9), (-18.0, 1.7, 0.7)), 384, 20),
+    ("atrium_2k", lambda: (scenes.atrium(2000)[0], (9.0, 1.5, -0.4), (-10.0, 1.6, 0.3)), 256, 12),
+    ("shoebox", lambda: (scenes.shoebox(), (0.0, 1.0, 2.0), (0.0, 1.0, 0.0)), 1000, 16),     # config C1 at full size
+]
+
+
+@pytest.mark.parametrize("name,make,nrays,nrefl", SEEDED, ids=[s[0] for s in SEEDED])
+def test_trace_matches_oracle_on_seeded_scenes(ctx, oracle, name, make, nrays, nrefl):
+    """BVH traversal must return exactly the brute-force winner (SURVEY §8(a) R2 tie rule)."""
+    scene, mic, src = make()
+    dirs = scenes.sphere_directions(nrays, seed=17)
+    ctx.set_scene(scene)
+    ctx.raytrace(mic, src, dirs, nrefl, AIR_COEFFICIENTS)
+    want, image, index = oracle.raytrace(scene, mic, src, dirs, nrefl, AIR_COEFFICIENTS)
+    assert_impulses_equal(ctx.get_raw_diffuse(), want, name)
+    for remove_direct in (False, True):
+        assert_impulses_equal(ctx.get_raw_images(remove_direct), oracle.collect_images(image, index, remove_direct), name + " images")
+    executed = int(np.count_nonzero(want["position"][:, :3].any(axis=1) | (want["time"] != 0) | want["volume"].any(axis=1)))
+    assert ctx.executed_bounces() >= executed
+
+
+def test_edge_cases_empty_and_ragged(ctx, oracle):
+    scene = scenes.rotated_square_room(n=1)
+    ctx.set_scene(scene)
+    # zero rays
+    ctx.raytrace((0, 2, 0), (0, 2, 2), np.zeros((0, 4), np.float32), 8, AIR_COEFFICIENTS)
+    assert ctx.get_raw_diffuse().shape[0] == 0 and ctx.get_image_candidates().shape[0] == 0
+    # a ragged count (not a multiple of the wave size) and a single reflection
+    dirs = scenes.sphere_directions(67, seed=3)
+    ctx.raytrace((0, 2, 0), (0, 2, 2), dirs, 1, AIR_COEFFICIENTS)
+    want, _, _ = oracle.raytrace(scene, (0, 2, 0), (0, 2, 2), dirs, 1, AIR_COEFFICIENTS)
+    assert_impulses_equal(ctx.get_raw_diffuse(), want)
+    # source outside the model: every ray escapes or hits from outside, must still agree
+    ctx.raytrace((0, 2, 0), (0, 200, 0), dirs, 4, AIR_COEFFICIENTS)
+    want, image, index = oracle.raytrace(scene, (0, 2, 0), (0, 200, 0), dirs, 4, AIR_COEFFICIENTS)
+    assert_impulses_equal(ctx.get_raw_diffuse(), want)
+    assert_impulses_equal(ctx.get_raw_images(False), oracle.collect_images(image, index, False))
+
+
+def test_scene_validation_rejects_bad_indices(ctx):
+    from parallel_reverb_raytracer_amd import capi
+    tri, vert, surf = scenes.rotated_square_room(n=1)
+    bad = tri.copy()
+    bad["v2"][3] = vert.shape[0]
+    with pytest.raises(capi.RvbError):
+        ctx.set_scene((bad, vert, surf))
+    ctx.set_scene((tri, vert, surf))
+
+
+def test_attenuate_speaker_matches_golden(ctx):
+    g = load_golden("attenuate_speaker")
+    for case in ("axis", "random"):
+        imp = golden_impulses(g, case)
+        for si in range(g["speaker_coefficient"].shape[0]):
+            out = ctx.attenuate_speaker(g[case + "_mic"], imp, g["speaker_direction"][si], float(g["speaker_coefficient"][si]))
+            assert np.array_equal(out["volume"], g["%s_s%d_volume" % (case, si)]), (case, si)
+            assert np.array_equal(out["time"], g["%s_s%d_time" % (case, si)]), (case, si)
+            assert not out["pad"].any()
+
+
+def test_attenuate_hrtf_matches_golden(ctx):
+    g = load_golden("attenuate_hrtf")
+    tables = {"test": scenes.hrtf_test_table(), "smooth": scenes.hrtf_synthetic_table()}
+    for case in ("axis", "random"):
+        imp = golden_impulses(g, case)
+        for ci in range(g["facing"].shape[0]):
+            for ch in (0, 1):
+                for tname, tab in tables.items():
+                    out = ctx.attenuate_hrtf(g[case + "_mic"], imp, tab[ch], g["facing"][ci], g["up"][ci], ch)
+                    key = "%s_c%d_ch%d_%s" % (case, ci, ch, tname)
+                    assert np.array_equal(out["volume"], g[key + "_volume"]), key
+                    assert np.array_equal(out["time"], g[key + "_time"]), key
+
+
+def test_attenuate_ragged_sizes(ctx, oracle):
+    rng = np.random.default_rng(4)
+    for n in (0, 1, 3, 15, 16, 17, 255, 1025):
+        imp = dtypes.aligned_zeros(n, IMPULSE)
+        imp["volume"] = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
+        imp["position"][:, :3] = rng.uniform(-9, 9, (n, 3)).astype(np.float32)
+        imp["time"] = rng.uniform(0.01, 2, n).astype(np.float32)
+        imp["volume"][::5] = 0
+        got = ctx.attenuate_speaker((1, 2, 3), imp, (0.3, -1, 0.2), 0.7)
+        want = oracle.attenuate_speaker((1, 2, 3), imp, (0.3, -1, 0.2), 0.7)
+        assert np.array_equal(got["volume"], want["volume"]) and np.array_equal(got["time"], want["time"]), n
+
+
+def test_flatten_is_bit_exact_with_serial_order(ctx, oracle):
+    """flattenImpulses (reference rayverb.cpp:48-77): float sums in impulse order."""
+    rng = np.random.default_rng(8)
+    for n in (0, 1, 1000, 40000):
+        att = dtypes.aligned_zeros(n, dtypes.ATTENUATED)
+        att["volume"] = (rng.uniform(-1, 1, (n, 8)) * rng.choice([1e-3, 1.0, 30.0], (n, 1))).astype(np.float32)
+        att["time"] = rng.uniform(0, 0.05, n).astype(np.float32)       # ~2200 bins: heavy collisions
+        got = ctx.flatten(att, 44100.0)
+        want = oracle.flatten(att, 44100.0)
+        assert got.shape == want.shape and np.array_equal(got, want), n
+
+
+def _oracle_ir(oracle, mic, impulses, speakers, trim, sr, hrtf=None):
+    if hrtf is None:
+        chans = [oracle.attenuate_speaker(mic, impulses, d, c) for d, c in speakers]
+    else:
+        table, facing, up = hrtf
+        chans = [oracle.attenuate_hrtf(mic, impulses, table[ch], facing, up, ch) for ch in (0, 1)]
+    if trim:
+        pd = oracle.find_predelay(chans)
+        for c in chans:
+            oracle.fix_predelay(c, pd)
+    flat = [oracle.flatten(c, sr) for c in chans]
+    nb = max(f.shape[1] for f in flat)
+    return flat, nb, chans
+
+
+@pytest.mark.parametrize("trim", [False, True])
+@pytest.mark.parametrize("model", ["speakers", "hrtf"])
+def test_fused_ir_exact_and_fast_modes(ctx, oracle, model, trim):
+    from parallel_reverb_raytracer_amd import capi
+    scene, info = scenes.cathedral(3000)
+    mic, src = info["mic"], info["source"]
+    dirs = scenes.sphere_directions(512, seed=23)
+    ctx.set_scene(scene)
+    ctx.raytrace(mic, src, dirs, 24, AIR_COEFFICIENTS)
+    images = ctx.get_raw_images(False)
+    all_raw = np.concatenate([ctx.get_raw_diffuse(), images])
+    speakers = [((-1, 0, -1), 0.5), ((1, 0, -1), 0.5)]
+    hrtf = (scenes.hrtf_synthetic_table(), (1.0, 0.0, 0.2), (0.0, 1.0, 0.0)) if model == "hrtf" else None
+    flat, nb, chans = _oracle_ir(oracle, mic, all_raw, speakers, trim, 44100.0, hrtf)
+    if hrtf is None:
+        ctx.ir_configure_speakers(mic, [s[0] for s in speakers], [s[1] for s in speakers], capi.IR_ALL, images)
+    else:
+        ctx.ir_configure_hrtf(mic, hrtf[0], hrtf[1], hrtf[2], capi.IR_ALL, images)
+    exact = ctx.ir_download(trim, 44100.0, capi.IR_EXACT)
+    # the reference bins every channel on its own maxtime; channels are compared over their own length
+    assert exact.shape[2] == nb
+    for ch in range(2):
+        n = flat[ch].shape[1]
+        assert np.array_equal(exact[ch][:, :n], flat[ch]), (model, trim, ch)
+        assert not exact[ch][:, n:].any()
+    fast = ctx.ir_download(trim, 44100.0, capi.IR_FAST)
+    assert fast.shape == exact.shape
+    # rounding bound for a re-ordered float sum: n_bin * eps * sum|terms| (+ the 1e-5 relative bar)
+    for ch in range(2):
+        bins = np.round(chans[ch]["time"] * np.float32(44100.0)).astype(np.int64)
+        absum = np.zeros((8, exact.shape[2]), np.float64)
+        count = np.zeros(exact.shape[2], np.float64)
+        np.add.at(count, bins, 1.0)
+        for b in range(8):
+            np.add.at(absum[b], bins, np.abs(chans[ch]["volume"][:, b].astype(np.float64)))
+        bound = 1e-5 * np.abs(exact[ch]) + count[None, :] * 2.0 ** -23 * absum + 1e-30
+        assert (np.abs(fast[ch].astype(np.float64) - exact[ch]) <= bound).all(), (model, trim, ch)
