@@ -9,7 +9,9 @@
 // float result of the triangle test can land slightly outside the true triangle / true distance.
 //
 // HBM layout (all arrays read-only during a trace, resident in L2 / Infinity Cache):
-//   nodes   : BvhNode[],   128 B, 4-wide, breadth-first (top levels contiguous), SoA boxes
+//   nodes   : BvhNode[],   128 B, 4-wide, breadth-first (top levels contiguous); one 32-byte
+//             record per child so that the four lanes that cooperate on one ray (trace_kernels.hip)
+//             read one contiguous 128-byte line per node visit
 //   tris    : BvhTri[],     48 B, in leaf order: v0, e0, e1 (edges precomputed), original index
 //   shade   : TriShade[],   16 B, by ORIGINAL triangle index: unit normal + surface index
 //   verts9  : TriCorners[], 48 B, by ORIGINAL triangle index: the three vertices (image-source)
@@ -26,12 +28,13 @@
 #define RVB_BVH_MAX_LEAF 4
 #define RVB_BVH_STACK 64            // per-lane traversal stack entries (LDS)
 
-struct BvhNode {                    // 128 B
-    float lox[4], loy[4], loz[4];
-    float hix[4], hiy[4], hiz[4];
-    uint32_t child[4];              // EMPTY | LEAF|(count-1)<<28|first | node index
-    uint32_t pad[4];
+struct BvhChild {                   // 32 B = two 16-byte loads
+    float lox, loy, loz, hix;
+    float hiy, hiz;
+    uint32_t ref;                   // EMPTY | LEAF|(count-1)<<28|first | node index
+    uint32_t pad;
 };
+struct BvhNode { BvhChild c[4]; };  // 128 B
 
 struct BvhTri {                     // 48 B
     float v0[3];

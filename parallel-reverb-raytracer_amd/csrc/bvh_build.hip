@@ -233,7 +233,7 @@ std::string rvb_build_scene(const rvb_triangle * triangles, uint64_t ntriangles,
     if (nprims == 0) {
         BvhNode root;
         std::memset(&root, 0, sizeof(root));
-        for (int c = 0; c < 4; ++c) root.child[c] = RVB_BVH_EMPTY;
+        for (int c = 0; c < 4; ++c) root.c[c].ref = RVB_BVH_EMPTY;
         out.nodes.push_back(root);
         out.depth = 1;
         return "";
@@ -301,24 +301,25 @@ std::string rvb_build_scene(const rvb_triangle * triangles, uint64_t ntriangles,
         BvhNode node;
         std::memset(&node, 0, sizeof(node));
         for (int k = 0; k < 4; ++k) {
+            BvhChild & slot = node.c[k];
             if (k >= nk) {
-                node.child[k] = RVB_BVH_EMPTY;
-                node.lox[k] = node.loy[k] = node.loz[k] = std::numeric_limits<float>::infinity();
-                node.hix[k] = node.hiy[k] = node.hiz[k] = -std::numeric_limits<float>::infinity();
+                slot.ref = RVB_BVH_EMPTY;
+                slot.lox = slot.loy = slot.loz = std::numeric_limits<float>::infinity();
+                slot.hix = slot.hiy = slot.hiz = -std::numeric_limits<float>::infinity();
                 continue;
             }
             const BinNode & c = b.nodes[kids[k]];
-            node.lox[k] = c.box.lo[0]; node.loy[k] = c.box.lo[1]; node.loz[k] = c.box.lo[2];
-            node.hix[k] = c.box.hi[0]; node.hiy[k] = c.box.hi[1]; node.hiz[k] = c.box.hi[2];
+            slot.lox = c.box.lo[0]; slot.loy = c.box.lo[1]; slot.loz = c.box.lo[2];
+            slot.hix = c.box.hi[0]; slot.hiy = c.box.hi[1]; slot.hiz = c.box.hi[2];
             if (c.leaf()) {
                 if (c.count > RVB_BVH_MAX_LEAF)
                     return "internal error: oversized BVH leaf";
-                node.child[k] = RVB_BVH_LEAF | ((c.count - 1) << 28) | c.first;
+                slot.ref = RVB_BVH_LEAF | ((c.count - 1) << 28) | c.first;
             } else {
-                uint32_t slot = (uint32_t) out.nodes.size();
+                uint32_t slot_index = (uint32_t) out.nodes.size();
                 out.nodes.emplace_back();
-                node.child[k] = slot;
-                q.push({kids[k], slot, it.depth + 1});
+                node.c[k].ref = slot_index;
+                q.push({kids[k], slot_index, it.depth + 1});
             }
         }
         out.nodes[it.slot] = node;
@@ -330,7 +331,7 @@ std::string rvb_build_scene(const rvb_triangle * triangles, uint64_t ntriangles,
     for (size_t i = out.nodes.size(); i-- > 0;) {
         uint32_t nchild = 0, deepest = 0;
         for (int k = 0; k < 4; ++k) {
-            uint32_t c = out.nodes[i].child[k];
+            uint32_t c = out.nodes[i].c[k].ref;
             if (c == RVB_BVH_EMPTY)
                 continue;
             ++nchild;

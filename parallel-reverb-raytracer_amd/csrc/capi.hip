@@ -50,6 +50,7 @@ struct rvb_ctx {
     SceneDev scene;
     uint64_t nnodes = 0, kept = 0;
     uint32_t depth = 0;
+    uint32_t stack_need = RVB_BVH_STACK;
 
     // rays + trace results
     DevBuf directions_own;
@@ -245,6 +246,7 @@ int rvb_set_scene(rvb_ctx * ctx, const rvb_triangle * triangles, uint64_t ntrian
     ctx->nnodes = built.nodes.size();
     ctx->kept = built.tris.size();
     ctx->depth = built.depth;
+    ctx->stack_need = built.stack_need;
     ctx->have_scene = true;
     return RVB_OK;
 }
@@ -317,6 +319,7 @@ int rvb_trace(rvb_ctx * ctx, const float mic[3], const float source[3], uint64_t
     a.executed = reinterpret_cast<unsigned long long *>(ctx->small.as<char>() + kSmallExecuted);
     a.nrays = nrays;
     a.nreflections = (uint32_t) nreflections;
+    a.stack_entries = ctx->stack_need;
     a.ray_offset = ray_offset;
     for (int i = 0; i < 3; ++i) { a.mic[i] = mic[i]; a.source[i] = source[i]; ctx->mic[i] = mic[i]; }
     for (int i = 0; i < 8; ++i) a.air[i] = air_coefficient[i];

@@ -28,6 +28,7 @@ struct TraceArgs {
     unsigned long long * executed;      // bounces executed
     uint64_t nrays;
     uint32_t nreflections;
+    uint32_t stack_entries;             // LDS traversal stack entries per lane (BuiltScene::stack_need)
     uint64_t ray_offset;
     float mic[3];
     float source[3];

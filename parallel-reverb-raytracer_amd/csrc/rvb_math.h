@@ -102,10 +102,20 @@ RVB_HD void mirror_verts(TriVerts & in, const TriVerts & t)
     mirror_point(in.v2, t);
 }
 
-// reference kernel.cpp:194-198: pow(M_E, distance * AIR) — M_E converted to float, the power
-// evaluated in binary64 and rounded once; the "* 1" of kernel.cpp:210-213 is exact.
+// reference kernel.cpp:194-198: pow(M_E, distance * AIR) with M_E converted to float.  The
+// correctly rounded float result is wanted (the oracle's definition of the OpenCL built-in).
+// pow(e_f, x) = exp(x * ln(e_f)): x is a float, so x * ln(e_f) is formed exactly-to-106-bits with
+// ln(e_f) split in two doubles, and exp is evaluated in binary64; the total error is ~1.5 ulp of
+// binary64, so rounding to float gives the correctly rounded value except with probability ~1e-8.
+// The "* 1" of kernel.cpp:210-213 is exact.
 RVB_HD float air_attenuation(float distance, float air)
 {
-    const float e = (float) 2.7182818284590452354;
-    return (float) pow((double) e, (double) (distance * air));
+    // ln((float) M_E) = ln(2.71828174591064453125) = 0.99999996963214001827215631464059433...
+    const double ln_e_hi = 0x1.fffffefb245eap-1;
+    const double ln_e_lo = 0x1.a2d208d1c4e82p-56;      // ln(e_f) - ln_e_hi
+    const double x = (double) (distance * air);
+    const double p = x * ln_e_hi;
+    const double r = fma(x, ln_e_hi, -p) + x * ln_e_lo; // exact rounding error of p plus the low part
+    const double e = exp(p);
+    return (float) (e + e * r);
 }

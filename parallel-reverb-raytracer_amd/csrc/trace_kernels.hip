@@ -1,28 +1,33 @@
 // trace_kernels.hip — the per-ray trace of reference rayverb/kernel.cpp:304-503 (kernel
 // `raytrace`), re-organised for CDNA4 as three kernels over one 4-wide BVH:
 //
-//   path_kernel    one lane per ray: the inherently sequential chain closest hit -> reflect
-//                  (kernel.cpp:359-375, :459-461, :478, :492-501).  Latency-bound; per bounce it
-//                  leaves a 64-byte work record in the ray's Impulse slot.
+//   path_kernel    the inherently sequential chain closest hit -> reflect (kernel.cpp:359-375,
+//                  :459-461, :478, :492-501).  Latency-bound: FOUR LANES PER RAY, so that 100k rays
+//                  are 6250 waves instead of 1563 and the chip has enough waves to hide the
+//                  dependent node fetches.  Per bounce it leaves a 64-byte work record in the
+//                  ray's Impulse slot.
 //   image_kernel   one lane per (ray, bounce < 9): image-source validation (kernel.cpp:379-457).
 //                  The reference does this inside the ray's loop; its inputs are only the
 //                  triangles the ray hit so far, so it parallelises 9x wider here.
-//   shadow_kernel  one lane per (ray, bounce): the diffuse shadow ray to the microphone and the
+//   shadow_kernel  four lanes per (ray, bounce): the diffuse shadow ray to the microphone and the
 //                  final Impulse (kernel.cpp:463-490).  nrays*nreflections independent any-hit
 //                  queries: this is where the chip fills up.
 //
-// Every triangle test is the reference's Möller–Trumbore arithmetic (rvb_math.h); the BVH only
-// prunes.  One wave per workgroup; the traversal stack lives in LDS ([entry][lane], no bank
-// conflicts), nodes/triangles are read straight from L2 / Infinity Cache with 16-byte loads.
+// Quad-cooperative traversal: the four lanes of a quad own the four children of a node (one
+// contiguous 128-byte line per visit, two 16-byte loads per lane) and the up-to-four triangles
+// of a leaf; they combine results with DPP quad_perm moves, never through memory.  The per-ray
+// stack lives in LDS, 4 bytes per entry.  Every triangle test is the reference's Möller–Trumbore
+// arithmetic (rvb_math.h); the BVH only prunes, so a query returns the brute-force answer.
 #include "kernels.h"
 #include "rvb_math.h"
 
 #define WAVE 64
+#define QUADS_PER_BLOCK 16          // rays (or records) per 64-lane workgroup in the quad kernels
 #define NONE 0xFFFFFFFFu
 
 namespace {
 
-struct Hit { float t; uint32_t tri; uint32_t surface; };
+struct Hit { float t; uint32_t tri; };
 
 __device__ __forceinline__ float clamp_inv(float d)
 {
@@ -30,44 +35,157 @@ __device__ __forceinline__ float clamp_inv(float d)
     return fminf(fmaxf(inv, -1e30f), 1e30f);      // keeps 0 * inf out of the slab test
 }
 
+// ---- DPP helpers: data movement inside a quad (lanes 4k .. 4k+3) --------------------------------
+template <int CTRL> __device__ __forceinline__ uint32_t dpp_u(uint32_t v)
+{
+    return (uint32_t) __builtin_amdgcn_mov_dpp((int) v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) { return __uint_as_float(dpp_u<CTRL>(__float_as_uint(v))); }
+#define QP_SWAP1 0xB1     // quad_perm [1,0,3,2]
+#define QP_SWAP2 0x4E     // quad_perm [2,3,0,1]
+#define QP_BCAST(k) ((k) * 0x55)
+template <int K> __device__ __forceinline__ float quad_bcast_f(float v) { return dpp_f<QP_BCAST(K)>(v); }
+template <int K> __device__ __forceinline__ uint32_t quad_bcast_u(uint32_t v) { return dpp_u<QP_BCAST(K)>(v); }
+
+// 4-bit mask of `pred` over this lane's quad
+__device__ __forceinline__ uint32_t quad_ballot(bool pred)
+{
+    const unsigned long long m = __ballot(pred);
+    return (uint32_t) (m >> (threadIdx.x & 60u)) & 0xFu;
+}
+
+// Slab test of one child box.  Boxes are padded by the builder (BuiltScene::pad), limit carries the
+// cull slack, so the test is conservative with respect to the float triangle test.
+__device__ __forceinline__ bool slab(const float4 a, const float4 b, const v3 o, const float ix, const float iy, const float iz,
+                                     const float limit, const float cull_abs, float & tn)
+{
+    const float tx0 = (a.x - o.x) * ix, tx1 = (a.w - o.x) * ix;
+    const float ty0 = (a.y - o.y) * iy, ty1 = (b.x - o.y) * iy;
+    const float tz0 = (a.z - o.z) * iz, tz1 = (b.y - o.z) * iz;
+    tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fminf(tz0, tz1));
+    const float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
+    return __float_as_uint(b.z) != RVB_BVH_EMPTY && tn <= tf && tf >= -cull_abs && tn <= limit;
+}
+
 // Closest hit (ANY = false): the brute-force winner of reference kernel.cpp:167-192.
 // Any hit (ANY = true): is there a triangle with EPSILON < distance <= tmax — the negation of
 // reference kernel.cpp:295 "(!inter.intersects) || inter.distance > mag".
+// All four lanes of the quad call this with identical o, d, tmax and get identical results.
+// stack: this ray's column of the LDS stack, entries QUADS_PER_BLOCK words apart.
 template <bool ANY>
-__device__ __forceinline__ bool traverse(const SceneDev & sc, const v3 o, const v3 d, const float tmax,
-                                         uint32_t * __restrict__ stack /* this lane's column, stride WAVE */, Hit & hit)
+__device__ __forceinline__ bool traverse_quad(const SceneDev & sc, const v3 o, const v3 d, const float tmax,
+                                              uint32_t * __restrict__ stack, Hit & hit)
 {
+    const uint32_t c = threadIdx.x & 3u;          // the child / leaf triangle this lane owns
     const float ix = clamp_inv(d.x), iy = clamp_inv(d.y), iz = clamp_inv(d.z);
     float best_t = ANY ? tmax : __builtin_inff();
-    uint32_t best_i = NONE, best_s = 0;
-    int sp = 0;
+    uint32_t best_i = NONE;
+    uint32_t sp = 0;
     uint32_t ref = 0;                             // root node
     for (;;) {
         while (!(ref & RVB_BVH_LEAF)) {
+            const float4 * n = reinterpret_cast<const float4 *>(sc.nodes + ref) + 2 * c;
+            const float4 a = n[0], b = n[1];
+            const float limit = best_t * (1.0f + sc.cull_rel) + sc.cull_abs;
+            float tn;
+            const bool ok = slab(a, b, o, ix, iy, iz, limit, sc.cull_abs, tn);
+            const uint32_t cref = __float_as_uint(b.z);
+            const uint32_t hits = quad_ballot(ok);
+            if (hits == 0) {
+                if (sp > 0) { --sp; ref = stack[sp * QUADS_PER_BLOCK]; } else ref = NONE;
+                continue;
+            }
+            uint32_t winner;
+            if (ANY) {
+                winner = __ffs(hits) - 1;         // any-hit does not care about visiting order
+            } else {
+                const float key = ok ? tn : __builtin_inff();
+                const float k1 = fminf(key, dpp_f<QP_SWAP1>(key));
+                const float kmin = fminf(k1, dpp_f<QP_SWAP2>(k1));
+                winner = __ffs(quad_ballot(ok && key == kmin)) - 1;   // nearest child first
+            }
+            const uint32_t rest = hits & ~(1u << winner);
+            if (ok && c != winner)
+                stack[(sp + __popc(rest & ((1u << c) - 1u))) * QUADS_PER_BLOCK] = cref;
+            sp += __popc(rest);
+            const uint32_t r0 = quad_bcast_u<0>(cref), r1 = quad_bcast_u<1>(cref), r2 = quad_bcast_u<2>(cref), r3 = quad_bcast_u<3>(cref);
+            ref = winner == 0 ? r0 : winner == 1 ? r1 : winner == 2 ? r2 : r3;
+        }
+        if (ref == NONE)
+            break;
+        const uint32_t first = ref & 0x0FFFFFFFu;
+        const uint32_t count = ((ref >> 28) & 7u) + 1u;
+        float dist = 0.0f;
+        uint32_t idx = NONE;
+        if (c < count) {
+            const float4 * tp = reinterpret_cast<const float4 *>(sc.tris + first + c);
+            const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+            dist = mt_intersect(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), o, d);
+            idx = __float_as_uint(tc.y);
+        }
+        if (ANY) {
+            if (quad_ballot(c < count && dist > RVB_EPSILON && dist <= tmax) != 0)
+                return true;
+        } else {
+            // kernel.cpp:180-188 — smallest distance wins, equal distances go to the lower index.
+            // Lexicographic (distance, index) minimum over the quad's valid lanes.
+            const bool valid = c < count && dist > RVB_EPSILON;
+            float rd = valid ? dist : __builtin_inff();
+            uint32_t ri = valid ? idx : NONE;
+            {
+                const float od = dpp_f<QP_SWAP1>(rd);
+                const uint32_t oi = dpp_u<QP_SWAP1>(ri);
+                if (od < rd || (od == rd && oi < ri)) { rd = od; ri = oi; }
+            }
+            {
+                const float od = dpp_f<QP_SWAP2>(rd);
+                const uint32_t oi = dpp_u<QP_SWAP2>(ri);
+                if (od < rd || (od == rd && oi < ri)) { rd = od; ri = oi; }
+            }
+            if (ri != NONE && (best_i == NONE || rd < best_t || (rd == best_t && ri < best_i))) {
+                best_t = rd;
+                best_i = ri;
+            }
+        }
+        if (sp > 0) { --sp; ref = stack[sp * QUADS_PER_BLOCK]; } else break;
+    }
+    if (ANY)
+        return false;
+    hit.t = best_t;
+    hit.tri = best_i;
+    return best_i != NONE;
+}
+
+// One-lane-per-query traversal (image_kernel): same tests, same rule, the lane walks all four
+// children itself.  stack: this lane's column, entries WAVE words apart.
+template <bool ANY>
+__device__ __forceinline__ bool traverse_lane(const SceneDev & sc, const v3 o, const v3 d, const float tmax,
+                                              uint32_t * __restrict__ stack, Hit & hit)
+{
+    const float ix = clamp_inv(d.x), iy = clamp_inv(d.y), iz = clamp_inv(d.z);
+    float best_t = ANY ? tmax : __builtin_inff();
+    uint32_t best_i = NONE;
+    int sp = 0;
+    uint32_t ref = 0;
+    for (;;) {
+        while (!(ref & RVB_BVH_LEAF)) {
             const float4 * n = reinterpret_cast<const float4 *>(sc.nodes + ref);
-            const float4 lox = n[0], loy = n[1], loz = n[2], hix = n[3], hiy = n[4], hiz = n[5];
-            const uint4 ch = reinterpret_cast<const uint4 *>(n)[6];
-            const float limit = best_t + (sc.cull_abs + sc.cull_rel * best_t);
+            const float limit = best_t * (1.0f + sc.cull_rel) + sc.cull_abs;
             float key[4];
-            uint32_t cref[4] = {ch.x, ch.y, ch.z, ch.w};
-            const float lx[4] = {lox.x, lox.y, lox.z, lox.w}, ly[4] = {loy.x, loy.y, loy.z, loy.w}, lz[4] = {loz.x, loz.y, loz.z, loz.w};
-            const float hx[4] = {hix.x, hix.y, hix.z, hix.w}, hy[4] = {hiy.x, hiy.y, hiy.z, hiy.w}, hz[4] = {hiz.x, hiz.y, hiz.z, hiz.w};
+            uint32_t cref[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                float tx0 = (lx[c] - o.x) * ix, tx1 = (hx[c] - o.x) * ix;
-                float ty0 = (ly[c] - o.y) * iy, ty1 = (hy[c] - o.y) * iy;
-                float tz0 = (lz[c] - o.z) * iz, tz1 = (hz[c] - o.z) * iz;
-                float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fminf(tz0, tz1));
-                float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
-                bool ok = cref[c] != RVB_BVH_EMPTY && tn <= tf && tf >= -sc.cull_abs && tn <= limit;
+                const float4 a = n[2 * c], b = n[2 * c + 1];
+                float tn;
+                const bool ok = slab(a, b, o, ix, iy, iz, limit, sc.cull_abs, tn);
                 key[c] = ok ? tn : __builtin_inff();
-                if (!ok) cref[c] = NONE;
+                cref[c] = ok ? __float_as_uint(b.z) : NONE;
             }
-            // sort the four children by entry distance (5-comparator network)
 #define RVB_CSWAP(a, b) { if (key[b] < key[a]) { float tk = key[a]; key[a] = key[b]; key[b] = tk; uint32_t tr = cref[a]; cref[a] = cref[b]; cref[b] = tr; } }
-            RVB_CSWAP(0, 1) RVB_CSWAP(2, 3) RVB_CSWAP(0, 2) RVB_CSWAP(1, 3) RVB_CSWAP(1, 2)
+            if (!ANY) {
+                RVB_CSWAP(0, 1) RVB_CSWAP(2, 3) RVB_CSWAP(0, 2) RVB_CSWAP(1, 3) RVB_CSWAP(1, 2)
+            }
 #undef RVB_CSWAP
-            // misses carry key = inf and sort last; push far-to-near, continue with the nearest
             if (cref[3] != NONE) { stack[sp * WAVE] = cref[3]; ++sp; }
             if (cref[2] != NONE) { stack[sp * WAVE] = cref[2]; ++sp; }
             if (cref[1] != NONE) { stack[sp * WAVE] = cref[1]; ++sp; }
@@ -77,7 +195,7 @@ __device__ __forceinline__ bool traverse(const SceneDev & sc, const v3 o, const 
                 --sp;
                 ref = stack[sp * WAVE];
             } else {
-                ref = NONE;                       // has the LEAF bit: leaves the inner loop
+                ref = NONE;
             }
         }
         if (ref == NONE)
@@ -86,64 +204,43 @@ __device__ __forceinline__ bool traverse(const SceneDev & sc, const v3 o, const 
         const uint32_t count = ((ref >> 28) & 7u) + 1u;
         for (uint32_t j = 0; j < count; ++j) {
             const float4 * tp = reinterpret_cast<const float4 *>(sc.tris + first + j);
-            const float4 a = tp[0], b = tp[1], c = tp[2];
-            const v3 v0 = mk3(a.x, a.y, a.z), e0 = mk3(a.w, b.x, b.y), e1 = mk3(b.z, b.w, c.x);
-            const float dist = mt_intersect(v0, e0, e1, o, d);
-            const uint32_t idx = __float_as_uint(c.y);
+            const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+            const float dist = mt_intersect(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), o, d);
+            const uint32_t idx = __float_as_uint(tc.y);
             if (ANY) {
                 if (dist > RVB_EPSILON && dist <= tmax)
                     return true;
-            } else {
-                // kernel.cpp:180-188 — smallest distance wins, equal distances go to the lower index
-                if (dist > RVB_EPSILON && (best_i == NONE || dist < best_t || (dist == best_t && idx < best_i))) {
-                    best_t = dist;
-                    best_i = idx;
-                    best_s = __float_as_uint(c.z);
-                }
+            } else if (dist > RVB_EPSILON && (best_i == NONE || dist < best_t || (dist == best_t && idx < best_i))) {
+                best_t = dist;
+                best_i = idx;
             }
         }
-        if (sp > 0) {
-            --sp;
-            ref = stack[sp * WAVE];
-        } else {
-            break;
-        }
+        if (sp > 0) { --sp; ref = stack[sp * WAVE]; } else break;
     }
     if (ANY)
         return false;
     hit.t = best_t;
     hit.tri = best_i;
-    hit.surface = best_s;
     return best_i != NONE;
-}
-
-// reference kernel.cpp:274-296 (point_intersection): is `point` visible from `begin`
-__device__ __forceinline__ bool point_visible(const SceneDev & sc, v3 begin, v3 point, uint32_t * stack, float & mag)
-{
-    const v3 b2p = point - begin;
-    mag = length3(b2p);
-    const v3 dir = normalize3(b2p);
-    Hit h;
-    return !traverse<true>(sc, begin, dir, mag, stack, h);
 }
 
 __device__ __forceinline__ v3 ld3(const float * p) { return mk3(p[0], p[1], p[2]); }
 
 // ------------------------------------------------------------------------------------------------
-// Work record left by path_kernel in impulses[ray*nrefl + bounce] (64 B, four 16-byte stores):
-//   [0..7]  newVol = -volume * specular                      (kernel.cpp:461)
-//   [8..10] intersection, [11] DIFF = |dot(normal, dir)|      (kernel.cpp:459, :478)
-//   [12]    newDist (cumulative path length)                  (kernel.cpp:460)
-//   [13]    surface index, [14] triangle index, [15] 1 = record valid
+// Work record left by path_kernel in impulses[ray*nrefl + bounce] (64 B; quad lane c stores chunk c):
+//   chunk 0,1  newVol = -volume * specular                        (kernel.cpp:461)
+//   chunk 2    intersection.xyz, DIFF = |dot(normal, dir)|         (kernel.cpp:459, :478)
+//   chunk 3    newDist, surface index, triangle index, 1 = valid   (kernel.cpp:460)
 // shadow_kernel turns it into the final Impulse in place.
 __global__ __launch_bounds__(WAVE) void path_kernel(TraceArgs a)
 {
-    __shared__ uint32_t stack_lds[RVB_BVH_STACK * WAVE];
-    const uint32_t lane = threadIdx.x;
-    const uint64_t ray = (uint64_t) blockIdx.x * WAVE + lane;
+    extern __shared__ __attribute__((aligned(16))) uint32_t stack_lds[];   // [stack_entries][QUADS_PER_BLOCK]
+    const uint32_t c = threadIdx.x & 3u;
+    const uint32_t q = threadIdx.x >> 2;
+    const uint64_t ray = (uint64_t) blockIdx.x * QUADS_PER_BLOCK + q;
     if (ray >= a.nrays)
-        return;
-    uint32_t * stack = stack_lds + lane;
+        return;                                   // whole quads leave together
+    uint32_t * stack = stack_lds + q;
 
     const float4 d4 = a.directions[ray];
     v3 o = ld3(a.source);
@@ -157,28 +254,32 @@ __global__ __launch_bounds__(WAVE) void path_kernel(TraceArgs a)
     uint32_t index = 0;
     for (; index < a.nreflections; ++index) {
         Hit h;
-        if (!traverse<false>(a.scene, o, d, 0.0f, stack, h))
+        if (!traverse_quad<false>(a.scene, o, d, 0.0f, stack, h))
             break;                                                   // kernel.cpp:372-375
         const float4 sh = reinterpret_cast<const float4 *>(a.scene.shade)[h.tri];
         const v3 normal = mk3(sh.x, sh.y, sh.z);
-        const float4 * sp = reinterpret_cast<const float4 *>(a.scene.surfaces + h.surface);
+        const uint32_t surface = __float_as_uint(sh.w);
+        const float4 * sp = reinterpret_cast<const float4 *>(a.scene.surfaces + surface);
         const float4 s0 = sp[0], s1 = sp[1];
         const v3 p = o + d * h.t;                                    // kernel.cpp:459
         const float new_dist = distance + h.t;                       // kernel.cpp:460
         vol[0] = -vol[0] * s0.x; vol[1] = -vol[1] * s0.y; vol[2] = -vol[2] * s0.z; vol[3] = -vol[3] * s0.w;
         vol[4] = -vol[4] * s1.x; vol[5] = -vol[5] * s1.y; vol[6] = -vol[6] * s1.z; vol[7] = -vol[7] * s1.w;
         const float diff = fabsf(dot3(normal, d));                   // kernel.cpp:478
-        out[4 * index + 0] = make_float4(vol[0], vol[1], vol[2], vol[3]);
-        out[4 * index + 1] = make_float4(vol[4], vol[5], vol[6], vol[7]);
-        out[4 * index + 2] = make_float4(p.x, p.y, p.z, diff);
-        out[4 * index + 3] = make_float4(new_dist, __uint_as_float(h.surface), __uint_as_float(h.tri), __uint_as_float(1u));
-        if (index < RVB_NUM_IMAGE_SOURCE - 1)
+        float4 chunk;
+        if (c == 0) chunk = make_float4(vol[0], vol[1], vol[2], vol[3]);
+        else if (c == 1) chunk = make_float4(vol[4], vol[5], vol[6], vol[7]);
+        else if (c == 2) chunk = make_float4(p.x, p.y, p.z, diff);
+        else chunk = make_float4(new_dist, __uint_as_float(surface), __uint_as_float(h.tri), __uint_as_float(1u));
+        out[4 * index + c] = chunk;
+        if (c == 0 && index < RVB_NUM_IMAGE_SOURCE - 1)
             a.early[ray * (RVB_NUM_IMAGE_SOURCE - 1) + index] = h.tri;
         d = reflect3(normal, d);                                     // kernel.cpp:492-499
         o = p;
         distance = new_dist;
     }
-    atomicAdd(a.executed, (unsigned long long) index);
+    if (c == 0)
+        atomicAdd(a.executed, (unsigned long long) index);
 }
 
 // reference kernel.cpp:243-265 (add_image) for a known-valid slot
@@ -207,9 +308,18 @@ __device__ __forceinline__ TriVerts load_corners(const SceneDev & sc, uint32_t t
     return t;
 }
 
+// reference kernel.cpp:274-296 (point_intersection), one lane
+__device__ __forceinline__ bool point_visible_lane(const SceneDev & sc, v3 begin, v3 point, uint32_t * stack)
+{
+    const v3 b2p = point - begin;
+    const float mag = length3(b2p);
+    Hit h;
+    return !traverse_lane<true>(sc, begin, normalize3(b2p), mag, stack, h);
+}
+
 __global__ __launch_bounds__(WAVE) void image_kernel(TraceArgs a)
 {
-    __shared__ uint32_t stack_lds[RVB_BVH_STACK * WAVE];
+    extern __shared__ __attribute__((aligned(16))) uint32_t stack_lds[];   // [stack_entries][WAVE]
     const uint32_t lane = threadIdx.x;
     uint32_t * stack = stack_lds + lane;
     const uint64_t g = (uint64_t) blockIdx.x * WAVE + lane;
@@ -222,8 +332,7 @@ __global__ __launch_bounds__(WAVE) void image_kernel(TraceArgs a)
         for (int b = 0; b < 4; ++b) direct.position[b] = 0.0f;
         direct.time = 0.0f;
         direct.pad_[0] = direct.pad_[1] = direct.pad_[2] = 0.0f;
-        float mag;
-        if (point_visible(a.scene, source, mic, stack, mag)) {
+        if (point_visible_lane(a.scene, source, mic, stack)) {
             float one[8] = {1, 1, 1, 1, 1, 1, 1, 1};
             make_image(a, mic, mic, source, one, direct);
         }
@@ -269,7 +378,7 @@ __global__ __launch_bounds__(WAVE) void image_kernel(TraceArgs a)
 
         const v3 idir = normalize3(ip - prev_intersection);
         Hit h;
-        const bool found = traverse<false>(a.scene, prev_intersection, idir, 0.0f, stack, h);
+        const bool found = traverse_lane<false>(a.scene, prev_intersection, idir, 0.0f, stack, h);
         const float hd = found ? h.t : 0.0f;                          // Intersection {0, 0, false}
         const v3 nip = prev_intersection + idir * hd;
         const bool lo = (nip.x - RVB_EPSILON < ip.x) && (nip.y - RVB_EPSILON < ip.y) && (nip.z - RVB_EPSILON < ip.z);
@@ -277,10 +386,8 @@ __global__ __launch_bounds__(WAVE) void image_kernel(TraceArgs a)
         intersects = found && lo && hi;
         prev_intersection = ip;
     }
-    if (intersects) {
-        float mag;
-        intersects = point_visible(a.scene, prev_intersection, mic, stack, mag);   // kernel.cpp:431-440
-    }
+    if (intersects)
+        intersects = point_visible_lane(a.scene, prev_intersection, mic, stack);   // kernel.cpp:431-440
     if (!intersects)
         return;
 
@@ -294,54 +401,60 @@ __global__ __launch_bounds__(WAVE) void image_kernel(TraceArgs a)
         volume[0] = v0.x; volume[1] = v0.y; volume[2] = v0.z; volume[3] = v0.w;
         volume[4] = v1.x; volume[5] = v1.y; volume[6] = v1.z; volume[7] = v1.w;
     }
-    rvb_image_candidate c;
-    c.ray = a.ray_offset + ray;
-    c.slot = index + 1;
-    c.index = tri_here + 1;
-    make_image(a, mic, mic_reflection, source, volume, c.impulse);
+    rvb_image_candidate cand;
+    cand.ray = a.ray_offset + ray;
+    cand.slot = index + 1;
+    cand.index = tri_here + 1;
+    make_image(a, mic, mic_reflection, source, volume, cand.impulse);
     const uint32_t at = atomicAdd(a.candidate_count, 1u);
-    a.candidates[at] = c;
+    a.candidates[at] = cand;
 }
 
 __global__ __launch_bounds__(WAVE) void shadow_kernel(TraceArgs a)
 {
-    __shared__ uint32_t stack_lds[RVB_BVH_STACK * WAVE];
-    const uint32_t lane = threadIdx.x;
-    uint32_t * stack = stack_lds + lane;
+    extern __shared__ __attribute__((aligned(16))) uint32_t stack_lds[];   // [stack_entries][QUADS_PER_BLOCK]
+    const uint32_t c = threadIdx.x & 3u;
+    const uint32_t q = threadIdx.x >> 2;
+    uint32_t * stack = stack_lds + q;
     const uint64_t total = a.nrays * (uint64_t) a.nreflections;
     const v3 mic = ld3(a.mic);
-    for (uint64_t g = (uint64_t) blockIdx.x * WAVE + lane; g < total; g += (uint64_t) gridDim.x * WAVE) {
+    // a.air[] for this lane's four bands (lanes 0/1 of the quad finish bands 0-3 / 4-7)
+    const float air0 = a.air[(c & 1u) * 4 + 0], air1 = a.air[(c & 1u) * 4 + 1];
+    const float air2 = a.air[(c & 1u) * 4 + 2], air3 = a.air[(c & 1u) * 4 + 3];
+    for (uint64_t g = (uint64_t) blockIdx.x * QUADS_PER_BLOCK + q; g < total; g += (uint64_t) gridDim.x * QUADS_PER_BLOCK) {
         float4 * rec = reinterpret_cast<float4 *>(a.impulses + g);
-        const float4 r3 = rec[3];
-        if (__float_as_uint(r3.w) != 1u)
+        const float4 mine = rec[c];               // the quad reads the 64-byte record as one line
+        // chunk 3 = (newDist, surface, triangle, valid); chunk 2 = (intersection, DIFF)
+        const uint32_t valid = quad_bcast_u<3>(__float_as_uint(mine.w));
+        if (valid != 1u)
             continue;                             // ray had already escaped: slot keeps its zero fill
-        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-        const v3 p = mk3(r2.x, r2.y, r2.z);
-        const float diff = r2.w;
-        const float new_dist = r3.x;
-        const uint32_t surface = __float_as_uint(r3.y);
+        const float new_dist = quad_bcast_f<3>(mine.x);
+        const uint32_t surface = quad_bcast_u<3>(__float_as_uint(mine.y));
+        const v3 p = mk3(quad_bcast_f<2>(mine.x), quad_bcast_f<2>(mine.y), quad_bcast_f<2>(mine.z));
+        const float diff = quad_bcast_f<2>(mine.w);
 
-        float mag;
-        const bool visible = point_visible(a.scene, p, mic, stack, mag);        // kernel.cpp:463-469
-        const float dist = visible ? new_dist + mag : 0.0f;                      // kernel.cpp:471
-        float4 o0 = make_float4(0, 0, 0, 0), o1 = make_float4(0, 0, 0, 0);
-        if (visible) {
-            const float4 * sp = reinterpret_cast<const float4 *>(a.scene.surfaces + surface);
-            const float4 d0 = sp[2], d1 = sp[3];                                  // diffuse coefficients
-            // kernel.cpp:480-485: newVol * attenuation * diffuse * DIFF, left to right
-            o0.x = ((r0.x * (air_attenuation(dist, a.air[0]) * 1.0f)) * d0.x) * diff;
-            o0.y = ((r0.y * (air_attenuation(dist, a.air[1]) * 1.0f)) * d0.y) * diff;
-            o0.z = ((r0.z * (air_attenuation(dist, a.air[2]) * 1.0f)) * d0.z) * diff;
-            o0.w = ((r0.w * (air_attenuation(dist, a.air[3]) * 1.0f)) * d0.w) * diff;
-            o1.x = ((r1.x * (air_attenuation(dist, a.air[4]) * 1.0f)) * d1.x) * diff;
-            o1.y = ((r1.y * (air_attenuation(dist, a.air[5]) * 1.0f)) * d1.y) * diff;
-            o1.z = ((r1.z * (air_attenuation(dist, a.air[6]) * 1.0f)) * d1.z) * diff;
-            o1.w = ((r1.w * (air_attenuation(dist, a.air[7]) * 1.0f)) * d1.w) * diff;
+        // kernel.cpp:463-469 point_intersection(intersection, mic)
+        const v3 b2p = mic - p;
+        const float mag = length3(b2p);
+        Hit h;
+        const bool visible = !traverse_quad<true>(a.scene, p, normalize3(b2p), mag, stack, h);
+        const float dist = visible ? new_dist + mag : 0.0f;          // kernel.cpp:471
+        float4 o = make_float4(0, 0, 0, 0);
+        if (c < 2) {
+            if (visible) {
+                const float4 dc = reinterpret_cast<const float4 *>(a.scene.surfaces + surface)[2 + c];   // diffuse
+                // kernel.cpp:480-485: newVol * attenuation * diffuse * DIFF, left to right
+                o.x = ((mine.x * (air_attenuation(dist, air0) * 1.0f)) * dc.x) * diff;
+                o.y = ((mine.y * (air_attenuation(dist, air1) * 1.0f)) * dc.y) * diff;
+                o.z = ((mine.z * (air_attenuation(dist, air2) * 1.0f)) * dc.z) * diff;
+                o.w = ((mine.w * (air_attenuation(dist, air3) * 1.0f)) * dc.w) * diff;
+            }
+        } else if (c == 2) {
+            o = make_float4(p.x, p.y, p.z, 0.0f);
+        } else {
+            o.x = seconds_per_meter() * dist;                        // kernel.cpp:489
         }
-        rec[0] = o0;
-        rec[1] = o1;
-        rec[2] = make_float4(p.x, p.y, p.z, 0.0f);
-        rec[3] = make_float4(seconds_per_meter() * dist, 0.0f, 0.0f, 0.0f);      // kernel.cpp:489
+        rec[c] = o;
     }
 }
 
@@ -350,22 +463,22 @@ __global__ __launch_bounds__(WAVE) void shadow_kernel(TraceArgs a)
 void rvb_launch_path(const TraceArgs & a, hipStream_t s)
 {
     if (a.nrays == 0) return;
-    const unsigned blocks = (unsigned) ((a.nrays + WAVE - 1) / WAVE);
-    hipLaunchKernelGGL(path_kernel, dim3(blocks), dim3(WAVE), 0, s, a);
+    const unsigned blocks = (unsigned) ((a.nrays + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK);
+    hipLaunchKernelGGL(path_kernel, dim3(blocks), dim3(WAVE), a.stack_entries * QUADS_PER_BLOCK * sizeof(uint32_t), s, a);
 }
 
 void rvb_launch_images(const TraceArgs & a, hipStream_t s)
 {
     const uint64_t work = a.nrays * (RVB_NUM_IMAGE_SOURCE - 1);
     const unsigned blocks = (unsigned) ((work + WAVE - 1) / WAVE);
-    hipLaunchKernelGGL(image_kernel, dim3(blocks ? blocks : 1), dim3(WAVE), 0, s, a);
+    hipLaunchKernelGGL(image_kernel, dim3(blocks ? blocks : 1), dim3(WAVE), a.stack_entries * WAVE * sizeof(uint32_t), s, a);
 }
 
 void rvb_launch_shadow(const TraceArgs & a, hipStream_t s)
 {
     const uint64_t total = a.nrays * (uint64_t) a.nreflections;
     if (total == 0) return;
-    uint64_t blocks = (total + WAVE - 1) / WAVE;
-    if (blocks > 256u * 64u) blocks = 256u * 64u;     // grid-stride beyond 64 waves per CU
-    hipLaunchKernelGGL(shadow_kernel, dim3((unsigned) blocks), dim3(WAVE), 0, s, a);
+    uint64_t blocks = (total + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK;
+    if (blocks > 256u * 256u) blocks = 256u * 256u;   // grid-stride beyond 256 single-wave workgroups per CU
+    hipLaunchKernelGGL(shadow_kernel, dim3((unsigned) blocks), dim3(WAVE), a.stack_entries * QUADS_PER_BLOCK * sizeof(uint32_t), s, a);
 }
