@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 import rvb_import  # noqa: E402
 
 rvb_import.load()
-from parallel_reverb_raytracer_amd import capi, dtypes, scenes  # noqa: E402
+from parallel_reverb_raytracer_amd import capi, distributed, dtypes, scenes  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
@@ -114,38 +114,14 @@ def main():
     state = {}
 
     def step(record):
-        ctx.trace(mic, src, nrefl, dtypes.AIR_COEFFICIENTS, ray_offset=rank * nrays)
-        cand = ctx.get_image_candidates()                 # small: valid image-source paths only
-        if record:
-            for k, v in ctx.last_timings():
-                kernel_ms.setdefault(k, []).append(v)
-        direct = ctx.get_direct()
-        if world > 1:
-            gathered = [None] * world
-            dist.all_gather_object(gathered, cand)
-            cand = np.concatenate(gathered)
-        images = capi.merge_images(cand, direct, False) if rank == 0 else np.zeros(0, dtypes.IMPULSE)
-        ctx.ir_configure_speakers(mic, speakers_dir, speakers_coeff, capi.IR_ALL, images)
-        lo, hi = ctx.ir_time_range()
-        if record:
-            for k, v in ctx.last_timings():
-                kernel_ms.setdefault(k, []).append(v)
-        if world > 1:
-            r = torch.tensor([-lo if lo > 0 else -3.0e38, hi], device=device, dtype=torch.float32)
-            dist.all_reduce(r, op=dist.ReduceOp.MAX)      # max(-min_nonzero), max
-            lo = float(-r[0]) if float(r[0]) > -3.0e38 else 0.0
-            hi = float(r[1])
-        nbins = ctx.ir_bins(hi, lo, sr)
-        hist = torch.zeros((2, 8, nbins), device=device, dtype=torch.float32)
-        torch.cuda.synchronize()
-        ctx.ir_accumulate(lo, sr, nbins, mode, hist.data_ptr())
-        if record:
-            for k, v in ctx.last_timings():
-                kernel_ms.setdefault(k, []).append(v)
-        ctx.synchronize()
-        if world > 1:
-            dist.all_reduce(hist, op=dist.ReduceOp.SUM)   # RCCL over xGMI: [2][8][nbins] floats
-        state.update(hist=hist, nbins=nbins, images=int(images.shape[0]), predelay=lo)
+        def on_stage(_name):
+            if record:
+                for k, v in ctx.last_timings():
+                    kernel_ms.setdefault(k, []).append(v)
+        hist, info = distributed.generate_ir(ctx, mic, src, nrefl, dtypes.AIR_COEFFICIENTS, speakers_dir, speakers_coeff, sr,
+                                             trim_predelay=True, mode=mode, rank=rank, world=world, ray_offset=rank * nrays,
+                                             device=device, on_stage=on_stage)
+        state.update(hist=hist, nbins=info["nbins"], images=info["images"], predelay=info["predelay"])
 
     def fence():
         ctx.synchronize()

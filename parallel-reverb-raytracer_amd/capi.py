@@ -263,6 +263,11 @@ class Context:
         self._check(self.lib.rvb_ir_accumulate(self.handle, ctypes.c_float(predelay), ctypes.c_float(sample_rate), _u64(nbins),
                                                ctypes.c_int(mode), _vp(device_histogram_pointer)))
 
+    def ir_accumulate_tensor(self, predelay, sample_rate, nbins, mode, tensor):
+        """Adds into a zeroed torch CUDA tensor [nchannels][8][nbins] (plumbing for distributed.py)."""
+        assert tensor.is_cuda and tensor.is_contiguous() and tensor.numel() == self.nchannels * 8 * nbins
+        self.ir_accumulate(predelay, sample_rate, nbins, mode, tensor.data_ptr())
+
     def ir_download(self, trim_predelay, sample_rate, mode=IR_FAST):
         """attenuate -> fixPredelay -> flattenImpulses (reference cmd/main.cpp:280-298) -> [nch][8][nbins]."""
         nbins = _u64(0)

@@ -1,0 +1,60 @@
+"""TEST INFRASTRUCTURE: a stand-in with the method surface of capi.Context whose compute is the CPU
+oracle.  It lets the multi-process orchestration of parallel_reverb_raytracer_amd.distributed run
+under gloo on machines without a GPU.  Never used by the product."""
+import numpy as np
+
+from parallel_reverb_raytracer_amd import capi
+from parallel_reverb_raytracer_amd.dtypes import ATTENUATED, IMPULSE, NUM_IMAGE_SOURCE
+
+
+class OracleTracer:
+    def __init__(self, oracle, scene, directions):
+        self.oracle, self.scene, self.directions = oracle, scene, directions
+        self.nchannels = 0
+
+    def trace(self, mic, source, nreflections, air, ray_offset=0):
+        self.mic = mic
+        self.diffuse, self.image, self.index = self.oracle.raytrace(self.scene, mic, source, self.directions, nreflections, air)
+        self.ray_offset = ray_offset
+
+    def get_image_candidates(self):
+        nrays = self.directions.shape[0]
+        idx = self.index.reshape(nrays, NUM_IMAGE_SOURCE)
+        rays, slots = np.nonzero(idx[:, 1:])
+        cand = np.zeros(rays.shape[0], dtype=capi.IMAGE_CANDIDATE)
+        cand["ray"], cand["slot"] = rays + self.ray_offset, slots + 1
+        cand["index"] = idx[rays, slots + 1]
+        cand["impulse"] = self.image.reshape(nrays, NUM_IMAGE_SOURCE)[rays, slots + 1]
+        return cand
+
+    def get_direct(self):
+        return self.image[:1].copy()
+
+    def ir_configure_speakers(self, mic, directions, coefficients, which, images):
+        parts = []
+        if which & capi.IR_DIFFUSE:
+            parts.append(self.diffuse)
+        if which & capi.IR_IMAGES:
+            parts.append(np.ascontiguousarray(images, dtype=IMPULSE))
+        self.impulses = np.concatenate(parts) if parts else np.zeros(0, IMPULSE)
+        self.channels = [self.oracle.attenuate_speaker(mic, self.impulses, d, c) for d, c in zip(directions, coefficients)]
+        self.nchannels = len(self.channels)
+
+    def ir_time_range(self):
+        t = np.concatenate([c["time"] for c in self.channels]) if self.channels else np.zeros(0, np.float32)
+        nz = t[t != 0]
+        return (float(nz.min()) if nz.size else 0.0), (float(t.max()) if t.size else 0.0)
+
+    def ir_bins(self, max_time, predelay, sample_rate):
+        t = np.float32(max_time) - np.float32(predelay) if max_time > predelay else np.float32(0)
+        return int(np.round(np.float32(t * np.float32(sample_rate))) + 1)
+
+    def ir_accumulate_tensor(self, predelay, sample_rate, nbins, mode, tensor):
+        for ch, att in enumerate(self.channels):
+            att = att.copy()
+            self.oracle.fix_predelay(att, predelay)
+            flat = self.oracle.flatten(att, sample_rate)
+            tensor[ch, :, :flat.shape[1]] += __import__("torch").from_numpy(flat)
+
+    def synchronize(self):
+        pass

@@ -1,0 +1,74 @@
+"""world_size-2 `gloo` test of the N>1 path (distributed.generate_ir): ray-range shards, candidate
+all-gather + lowest-ray-wins merge, time-range all-reduce, histogram all-reduce(sum).  The per-rank
+compute is the CPU oracle (tests/oracle_tracer.py), so this runs without a GPU."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out_dir, total_rays, nrefl):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import rvb_import
+    rvb_import.load()
+    import torch.distributed as dist
+    import pyoracle
+    from oracle_tracer import OracleTracer
+    from parallel_reverb_raytracer_amd import capi, distributed, dtypes, scenes
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    scene, info = scenes.cathedral(1200)
+    first, count = distributed.shard_range(total_rays, rank, world)
+    dirs = scenes.sphere_directions(count, seed=9, first=first)
+    tracer = OracleTracer(pyoracle.Oracle("port"), scene, dirs)
+    hist, meta = distributed.generate_ir(tracer, info["mic"], info["source"], nrefl, dtypes.AIR_COEFFICIENTS,
+                                         [(-1, 0, -1), (1, 0, -1)], [0.5, 0.5], 44100.0, trim_predelay=True,
+                                         mode=capi.IR_EXACT, rank=rank, world=world, ray_offset=first, device="cpu")
+    np.savez(os.path.join(out_dir, "rank%d_of%d.npz" % (rank, world)), hist=hist.numpy(), nbins=meta["nbins"],
+             predelay=meta["predelay"], images=meta["images"])
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_shard_range_partitions_exactly():
+    from parallel_reverb_raytracer_amd import distributed
+    for total in (0, 1, 7, 64, 100000, 1000003):
+        for world in (1, 2, 3, 8):
+            got = [distributed.shard_range(total, r, world) for r in range(world)]
+            assert sum(c for _, c in got) == total
+            assert all(got[r][0] + got[r][1] == got[r + 1][0] for r in range(world - 1)) and got[0][0] == 0
+            assert max(c for _, c in got) - min(c for _, c in got) <= 1
+
+
+def test_two_rank_gloo_equals_single_process(tmp_path, oracle):
+    import torch.multiprocessing as mp
+    total_rays, nrefl = 96, 10
+    _worker(0, 1, 0, str(tmp_path), total_rays, nrefl)
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), total_rays, nrefl), nprocs=2, join=True)
+    one = np.load(os.path.join(str(tmp_path), "rank0_of1.npz"))
+    two = [np.load(os.path.join(str(tmp_path), "rank%d_of2.npz" % r)) for r in (0, 1)]
+    # both ranks hold the same reduced histogram, binned with the global predelay / global length
+    assert np.array_equal(two[0]["hist"], two[1]["hist"])
+    assert int(two[0]["nbins"]) == int(one["nbins"]) and float(two[0]["predelay"]) == float(one["predelay"])
+    assert int(two[0]["images"]) == int(one["images"]) and int(two[1]["images"]) == 0     # only rank 0 adds the merged images
+    # the shard sums differ from the serial order only by float re-association
+    a, b = one["hist"].astype(np.float64), two[0]["hist"].astype(np.float64)
+    scale = np.abs(a).max(axis=2, keepdims=True) + 1e-30
+    assert (np.abs(a - b) <= 1e-5 * scale).all()
+    assert np.abs(a).sum() > 0
