@@ -155,6 +155,9 @@ int rvb_ir_download(rvb_ctx * ctx, int trim_predelay, float sample_rate, int mod
  * Durations in milliseconds of the kernels of the last rvb_trace / rvb_ir_accumulate, taken with
  * HIP events on the context's stream; names is a ';'-separated list matching ms[]. */
 int rvb_last_timings(rvb_ctx * ctx, char * names, uint64_t names_capacity, float * ms, uint64_t ms_capacity, uint64_t * count);
+/* In-kernel cycle stamps of the last trace; all zero unless the library was built with -DRVB_STAMPS=1
+ * (diagnostic build, never the shipped one).  out[0..15] path_kernel, out[16..31] shadow_kernel. */
+int rvb_debug_stamps(rvb_ctx * ctx, uint64_t * out, uint64_t capacity);
 /* Number of bounces actually executed by the last trace (escaped rays stop early). */
 int rvb_executed_bounces(rvb_ctx * ctx, uint64_t * bounces);
 

@@ -13,7 +13,7 @@ import numpy as np
 from .dtypes import ATTENUATED, IMPULSE, SPEAKER, aligned_zeros
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librvb_hip.so")
+LIB_PATH = os.environ.get("RVB_LIB", os.path.join(_HERE, "librvb_hip.so"))   # RVB_LIB: A/B builds of the same ABI
 
 IMAGE_CANDIDATE = np.dtype([("ray", "<u8"), ("slot", "<u4"), ("index", "<u4"), ("impulse", IMPULSE)])
 assert IMAGE_CANDIDATE.itemsize == 80
@@ -28,7 +28,7 @@ SYMBOLS = [
     "rvb_get_diffuse", "rvb_diffuse_device", "rvb_get_direct", "rvb_get_image_candidates", "rvb_merge_images",
     "rvb_attenuate_speaker", "rvb_attenuate_hrtf", "rvb_flatten",
     "rvb_ir_configure_speakers", "rvb_ir_configure_hrtf", "rvb_ir_time_range", "rvb_ir_bins", "rvb_ir_accumulate",
-    "rvb_ir_download", "rvb_last_timings", "rvb_executed_bounces",
+    "rvb_ir_download", "rvb_last_timings", "rvb_debug_stamps", "rvb_executed_bounces",
 ]
 
 _vp = ctypes.c_void_p
@@ -198,6 +198,11 @@ class Context:
         v = _u64(0)
         self._check(self.lib.rvb_executed_bounces(self.handle, ctypes.byref(v)))
         return v.value
+
+    def debug_stamps(self):
+        out = (ctypes.c_uint64 * 32)()
+        self._check(self.lib.rvb_debug_stamps(self.handle, out, _u64(32)))
+        return [int(x) for x in out]
 
     def last_timings(self):
         names = ctypes.create_string_buffer(1024)

@@ -233,7 +233,11 @@ std::string rvb_build_scene(const rvb_triangle * triangles, uint64_t ntriangles,
     if (nprims == 0) {
         BvhNode root;
         std::memset(&root, 0, sizeof(root));
-        for (int c = 0; c < 4; ++c) root.c[c].ref = RVB_BVH_EMPTY;
+        for (int c = 0; c < 4; ++c) {
+            root.c[c].ref = RVB_BVH_EMPTY;
+            root.c[c].lox = root.c[c].loy = root.c[c].loz = root.c[c].hix = root.c[c].hiy = root.c[c].hiz =
+                std::numeric_limits<float>::quiet_NaN();
+        }
         out.nodes.push_back(root);
         out.depth = 1;
         return "";
@@ -304,8 +308,9 @@ std::string rvb_build_scene(const rvb_triangle * triangles, uint64_t ntriangles,
             BvhChild & slot = node.c[k];
             if (k >= nk) {
                 slot.ref = RVB_BVH_EMPTY;
-                slot.lox = slot.loy = slot.loz = std::numeric_limits<float>::infinity();
-                slot.hix = slot.hiy = slot.hiz = -std::numeric_limits<float>::infinity();
+                // empty slot: rejected by its ref in the slab test; the box is never used
+                slot.lox = slot.loy = slot.loz = std::numeric_limits<float>::quiet_NaN();
+                slot.hix = slot.hiy = slot.hiz = std::numeric_limits<float>::quiet_NaN();
                 continue;
             }
             const BinNode & c = b.nodes[kids[k]];

@@ -59,7 +59,7 @@ struct rvb_ctx {
     bool traced = false;
     uint64_t nreflections = 0;
     float mic[3] = {0, 0, 0};
-    DevBuf impulses, early, candidates, small;       // small: [0] candidate count, [2..3] executed, [16..] direct, range
+    DevBuf impulses, early, candidates, small, stamps;       // small: [0] candidate count, [2..3] executed, [16..] direct, range
     std::vector<Timing> timings;
     std::vector<hipEvent_t> event_pool;
     size_t events_used = 0;
@@ -177,7 +177,7 @@ void rvb_destroy(rvb_ctx * ctx)
     (void) hipSetDevice(ctx->device);
     if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
     for (DevBuf * b : {&ctx->nodes, &ctx->tris, &ctx->shade, &ctx->corners, &ctx->surfaces, &ctx->directions_own, &ctx->impulses,
-                       &ctx->early, &ctx->candidates, &ctx->small, &ctx->images, &ctx->hrtf_table, &ctx->acc, &ctx->keys_a,
+                       &ctx->early, &ctx->candidates, &ctx->small, &ctx->stamps, &ctx->images, &ctx->hrtf_table, &ctx->acc, &ctx->keys_a,
                        &ctx->keys_b, &ctx->vals_a, &ctx->vals_b, &ctx->sort_temp, &ctx->scratch_in, &ctx->scratch_out, &ctx->hist})
         b->release();
     for (hipEvent_t e : ctx->event_pool) (void) hipEventDestroy(e);
@@ -324,13 +324,20 @@ int rvb_trace(rvb_ctx * ctx, const float mic[3], const float source[3], uint64_t
     for (int i = 0; i < 3; ++i) { a.mic[i] = mic[i]; a.source[i] = source[i]; ctx->mic[i] = mic[i]; }
     for (int i = 0; i < 8; ++i) a.air[i] = air_coefficient[i];
 
+    // diagnostic builds (RVB_STAMPS): [0..15] path_kernel, [16..31] shadow_kernel
+    RVB_HIP(ctx, ctx->stamps.ensure(32 * sizeof(unsigned long long)));
+    RVB_HIP(ctx, hipMemsetAsync(ctx->stamps.p, 0, 32 * sizeof(unsigned long long), ctx->stream));
+    a.scene.stamps = ctx->stamps.as<unsigned long long>();
+
     ctx->reset_timings();
     ctx->begin_timing("path_kernel");
     rvb_launch_path(a, ctx->stream);
     ctx->end_timing();
     ctx->begin_timing("image_kernel");
+    a.scene.stamps = nullptr;
     rvb_launch_images(a, ctx->stream);
     ctx->end_timing();
+    a.scene.stamps = ctx->stamps.as<unsigned long long>() + 16;
     ctx->begin_timing("shadow_kernel");
     rvb_launch_shadow(a, ctx->stream);
     ctx->end_timing();
@@ -733,6 +740,18 @@ int rvb_last_timings(rvb_ctx * ctx, char * names, uint64_t names_capacity, float
         std::strncpy(names, joined.c_str(), names_capacity - 1);
         names[names_capacity - 1] = 0;
     }
+    return RVB_OK;
+}
+
+int rvb_debug_stamps(rvb_ctx * ctx, uint64_t * out, uint64_t capacity)
+{
+    if (!ctx || !out) return RVB_ERR_INVALID;
+    if (!ctx->traced) return fail(ctx, RVB_ERR_STATE, "rvb_debug_stamps: nothing traced");
+    RVB_BIND(ctx);
+    RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned long long v[32];
+    RVB_HIP(ctx, hipMemcpy(v, ctx->stamps.p, sizeof(v), hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < capacity && i < 32; ++i) out[i] = v[i];
     return RVB_OK;
 }
 

@@ -15,6 +15,7 @@ struct SceneDev {                       // device pointers of the current scene
     const rvb_surface * surfaces = nullptr;
     float cull_abs = 0.0f;              // slack added to the running closest distance when culling
     float cull_rel = 0.0f;
+    unsigned long long * stamps = nullptr;   // diagnostic builds only (RVB_STAMPS)
 };
 
 struct TraceArgs {

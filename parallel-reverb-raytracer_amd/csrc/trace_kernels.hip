@@ -21,13 +21,51 @@
 #include "kernels.h"
 #include "rvb_math.h"
 
+#include <cstdlib>
+
+#ifndef RVB_PATH_JOBS
+#define RVB_PATH_JOBS 1
+#endif
+#ifndef RVB_SHADOW_JOBS
+#define RVB_SHADOW_JOBS 0
+#endif
+
 #define WAVE 64
 #define QUADS_PER_BLOCK 16          // rays (or records) per 64-lane workgroup in the quad kernels
 #define NONE 0xFFFFFFFFu
 
 namespace {
 
+// Diagnostic build only (-DRVB_STAMPS=1, never shipped): per-wave s_memtime shares of the traversal
+// loop, written to a side buffer that no other code reads (cdna_hip_programming.md §7 "In-kernel stamps").
+#ifndef RVB_STAMPS
+#define RVB_STAMPS 0
+#endif
+#if RVB_STAMPS
+#define STAMP(var) { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); }
+struct Stamps {
+    unsigned long long node_steps = 0, node_cycles = 0, leaf_steps = 0, leaf_cycles = 0, done_calls = 0, done_cycles = 0;
+    unsigned long long quad_node_steps = 0, quad_leaf_steps = 0, t0 = 0;
+};
+#else
+#define STAMP(var)
+#endif
+
 struct Hit { float t; uint32_t tri; };
+
+// Streaming accesses to the 64-byte work records / Impulses (written once, read once): non-temporal,
+// so that the 819 MB stream does not evict the ~7 MB scene from the 4 MiB per-XCD L2s.
+typedef float nt_float4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_stream(float4 * p, const float4 v)
+{
+    nt_float4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<nt_float4 *>(p));
+}
+__device__ __forceinline__ float4 load_stream(const float4 * p)
+{
+    const nt_float4 t = __builtin_nontemporal_load(reinterpret_cast<const nt_float4 *>(p));
+    return make_float4(t.x, t.y, t.z, t.w);
+}
 
 __device__ __forceinline__ float clamp_inv(float d)
 {
@@ -54,106 +92,201 @@ __device__ __forceinline__ uint32_t quad_ballot(bool pred)
     return (uint32_t) (m >> (threadIdx.x & 60u)) & 0xFu;
 }
 
-// Slab test of one child box.  Boxes are padded by the builder (BuiltScene::pad), limit carries the
-// cull slack, so the test is conservative with respect to the float triangle test.
-__device__ __forceinline__ bool slab(const float4 a, const float4 b, const v3 o, const float ix, const float iy, const float iz,
-                                     const float limit, const float cull_abs, float & tn)
+// Slab test of one child box, t = lo*inv - o*inv as one FMA per plane.  Boxes are padded by the
+// builder (BuiltScene::pad) and `limit` carries the cull slack, so the test is conservative with
+// respect to the float triangle test (the FMA form moves a plane by <2e-3 of the padding).
+// Folded: tn = max(entry, -cull_abs), tf = min(exit, limit); hit iff tn <= tf.  Empty child slots
+// are rejected by their ref (minNum/maxNum would swallow a NaN box: max(NaN, -cull) = -cull).
+__device__ __forceinline__ bool slab(const float4 a, const float4 b, const float ix, const float iy, const float iz,
+                                     const float oix, const float oiy, const float oiz,
+                                     const float limit, const float neg_cull, float & tn)
 {
-    const float tx0 = (a.x - o.x) * ix, tx1 = (a.w - o.x) * ix;
-    const float ty0 = (a.y - o.y) * iy, ty1 = (b.x - o.y) * iy;
-    const float tz0 = (a.z - o.z) * iz, tz1 = (b.y - o.z) * iz;
-    tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fminf(tz0, tz1));
-    const float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
-    return __float_as_uint(b.z) != RVB_BVH_EMPTY && tn <= tf && tf >= -cull_abs && tn <= limit;
+    const float tx0 = fmaf(a.x, ix, -oix), tx1 = fmaf(a.w, ix, -oix);
+    const float ty0 = fmaf(a.y, iy, -oiy), ty1 = fmaf(b.x, iy, -oiy);
+    const float tz0 = fmaf(a.z, iz, -oiz), tz1 = fmaf(b.y, iz, -oiz);
+    tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), neg_cull));
+    const float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), limit));
+    return tn <= tf && __float_as_uint(b.z) != RVB_BVH_EMPTY;
 }
 
 // Closest hit (ANY = false): the brute-force winner of reference kernel.cpp:167-192.
 // Any hit (ANY = true): is there a triangle with EPSILON < distance <= tmax — the negation of
 // reference kernel.cpp:295 "(!inter.intersects) || inter.distance > mag".
-// All four lanes of the quad call this with identical o, d, tmax and get identical results.
-// stack: this ray's column of the LDS stack, entries QUADS_PER_BLOCK words apart.
+//
+// Persistent job loop: a quad asks its Job for a query (job.next), traverses, hands the result
+// back (job.done) and immediately asks for the next one, while the other quads of the wave keep
+// traversing their own queries.  No quad ever waits for the slowest ray of its wave at a bounce /
+// record boundary; the wave ends when every quad has run out of jobs.
+//   bool Job::next(v3 & o, v3 & d, float & tmax)   set up the quad's next query, false = none left
+//   void Job::done(bool hit, const Hit & h)          consume the result (quad-uniform control flow)
+// stack: this quad's column of the LDS stack, entries QUADS_PER_BLOCK words apart.
+template <bool ANY, class Job>
+__device__ __forceinline__ void traverse_jobs(const SceneDev & sc, uint32_t * __restrict__ stack, Job & job)
+{
+    const uint32_t c = threadIdx.x & 3u;          // the child / leaf triangle this lane owns
+    const uint32_t lane_base4 = (threadIdx.x & 60u) << 2;         // ds_bpermute address of the quad's lane 0
+    const uint32_t lt_mask = (1u << c) - 1u;
+    const char * node_base = reinterpret_cast<const char *>(sc.nodes) + 32u * c;
+    const float neg_cull = -sc.cull_abs, cull_scale = 1.0f + sc.cull_rel;
+    v3 o = mk3(0, 0, 0), d = mk3(0, 0, 0);
+    float tmax = 0.0f;
+    float ix = 0.0f, iy = 0.0f, iz = 0.0f, oix = 0.0f, oiy = 0.0f, oiz = 0.0f, best_t = 0.0f;
+    uint32_t best_i = NONE, sp = 0, ref = 0;
+#if RVB_STAMPS
+    Stamps st;
+    unsigned long long ta = 0, tb = 0;
+    STAMP(st.t0)
+#endif
+    bool active = job.next(o, d, tmax);
+#define RVB_RESET_QUERY()                                                         \
+    {                                                                             \
+        ix = clamp_inv(d.x); iy = clamp_inv(d.y); iz = clamp_inv(d.z);            \
+        oix = o.x * ix; oiy = o.y * iy; oiz = o.z * iz;                           \
+        best_t = ANY ? tmax : __builtin_inff();                                   \
+        best_i = NONE; sp = 0; ref = 0;                                           \
+    }
+    if (active) RVB_RESET_QUERY()
+    while (active) {
+        while (!(ref & RVB_BVH_LEAF)) {
+            STAMP(ta)
+#if RVB_STAMPS
+            st.quad_node_steps += (threadIdx.x & 3u) == 0 ? 1 : 0;
+#endif
+            const float4 * n = reinterpret_cast<const float4 *>(node_base + ((size_t) ref << 7));
+            const float4 a = n[0], b = n[1];
+            const float limit = fmaf(best_t, cull_scale, sc.cull_abs);
+            float tn;
+            const bool ok = slab(a, b, ix, iy, iz, oix, oiy, oiz, limit, neg_cull, tn);
+            const uint32_t cref = __float_as_uint(b.z);
+            // key = entry distance (two mantissa bits traded for the lane id): the quad minimum names
+            // the nearest hit child and the lane that owns it in two DPP steps
+            uint32_t key = ok ? ((__float_as_uint(fmaxf(tn, 0.0f)) & ~3u) | c) : NONE;
+            if (ANY) key = ok ? c : NONE;         // any-hit does not care about visiting order
+            uint32_t kmin = min(key, dpp_u<QP_SWAP1>(key));
+            kmin = min(kmin, dpp_u<QP_SWAP2>(kmin));
+            if (kmin == NONE) {
+                if (sp > 0) { --sp; ref = stack[sp * QUADS_PER_BLOCK]; } else ref = NONE;
+#if RVB_STAMPS
+                STAMP(tb)
+                st.node_steps += 1; st.node_cycles += tb - ta;
+#endif
+                continue;
+            }
+            const uint32_t winner = kmin & 3u;
+            const uint32_t rest = quad_ballot(ok) & ~(1u << winner);
+            if (ok && c != winner)
+                stack[(sp + __popc(rest & lt_mask)) * QUADS_PER_BLOCK] = cref;
+            sp += __popc(rest);
+            ref = (uint32_t) __builtin_amdgcn_ds_bpermute((int) (lane_base4 + (winner << 2)), (int) cref);
+#if RVB_STAMPS
+            STAMP(tb)
+            st.node_steps += 1; st.node_cycles += tb - ta;
+#endif
+        }
+        STAMP(ta)
+        bool finished = true, found = false;
+        if (ref != NONE) {
+            const uint32_t first = ref & 0x0FFFFFFFu;
+            const uint32_t count = ((ref >> 28) & 7u) + 1u;
+            float dist = 0.0f;
+            uint32_t idx = NONE;
+            if (c < count) {
+                const float4 * tp = reinterpret_cast<const float4 *>(sc.tris + first + c);
+                const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+                dist = mt_intersect(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), o, d);
+                idx = __float_as_uint(tc.y);
+            }
+            if (ANY) {
+                found = quad_ballot(c < count && dist > RVB_EPSILON && dist <= tmax) != 0;
+            } else {
+                // kernel.cpp:180-188 — smallest distance wins, equal distances go to the lower index.
+                // Lexicographic (distance, index) minimum over the quad's valid lanes.
+                const bool valid = c < count && dist > RVB_EPSILON;
+                float rd = valid ? dist : __builtin_inff();
+                uint32_t ri = valid ? idx : NONE;
+                {
+                    const float od = dpp_f<QP_SWAP1>(rd);
+                    const uint32_t oi = dpp_u<QP_SWAP1>(ri);
+                    if (od < rd || (od == rd && oi < ri)) { rd = od; ri = oi; }
+                }
+                {
+                    const float od = dpp_f<QP_SWAP2>(rd);
+                    const uint32_t oi = dpp_u<QP_SWAP2>(ri);
+                    if (od < rd || (od == rd && oi < ri)) { rd = od; ri = oi; }
+                }
+                if (ri != NONE && (best_i == NONE || rd < best_t || (rd == best_t && ri < best_i))) {
+                    best_t = rd;
+                    best_i = ri;
+                }
+            }
+            if (!found && sp > 0) {
+                --sp;
+                ref = stack[sp * QUADS_PER_BLOCK];
+                finished = false;
+            }
+        }
+#if RVB_STAMPS
+        STAMP(tb)
+        st.leaf_steps += 1; st.leaf_cycles += tb - ta;
+        st.quad_leaf_steps += ((threadIdx.x & 3u) == 0 && ref != NONE) ? 1 : 0;
+#endif
+        if (finished) {
+            STAMP(ta)
+            Hit h;
+            h.t = best_t;
+            h.tri = best_i;
+            job.done(ANY ? found : best_i != NONE, h);
+            active = job.next(o, d, tmax);
+            if (active) RVB_RESET_QUERY()
+#if RVB_STAMPS
+            STAMP(tb)
+            st.done_calls += 1; st.done_cycles += tb - ta;
+#endif
+        }
+    }
+#if RVB_STAMPS
+    if (sc.stamps) {
+        STAMP(tb)
+        // wave-level values are the maximum over lanes (a lane counts the wave steps it took part in)
+        unsigned long long v[9] = {st.node_steps, st.node_cycles, st.leaf_steps, st.leaf_cycles, st.done_calls, st.done_cycles,
+                                   tb - st.t0, st.quad_node_steps, st.quad_leaf_steps};
+        for (int i = 0; i < 7; ++i) {
+            unsigned long long m = v[i];
+            for (int off = 32; off > 0; off >>= 1) { unsigned long long o2 = __shfl_xor(m, off); m = o2 > m ? o2 : m; }
+            if ((threadIdx.x & 63u) == 0) atomicAdd(sc.stamps + i, m);
+        }
+        atomicAdd(sc.stamps + 7, v[7]);
+        atomicAdd(sc.stamps + 8, v[8]);
+        if ((threadIdx.x & 63u) == 0) atomicAdd(sc.stamps + 9, 1ull);
+    }
+#endif
+#undef RVB_RESET_QUERY
+}
+
+// A single query through the same loop (the quad's lanes return together).
+struct OneShotJob {
+    v3 o, d;
+    float tmax;
+    bool pending, hit;
+    Hit result;
+    __device__ __forceinline__ bool next(v3 & o_, v3 & d_, float & tmax_)
+    {
+        if (!pending) return false;
+        pending = false;
+        o_ = o; d_ = d; tmax_ = tmax;
+        return true;
+    }
+    __device__ __forceinline__ void done(bool h, const Hit & r) { hit = h; result = r; }
+};
+
 template <bool ANY>
 __device__ __forceinline__ bool traverse_quad(const SceneDev & sc, const v3 o, const v3 d, const float tmax,
                                               uint32_t * __restrict__ stack, Hit & hit)
 {
-    const uint32_t c = threadIdx.x & 3u;          // the child / leaf triangle this lane owns
-    const float ix = clamp_inv(d.x), iy = clamp_inv(d.y), iz = clamp_inv(d.z);
-    float best_t = ANY ? tmax : __builtin_inff();
-    uint32_t best_i = NONE;
-    uint32_t sp = 0;
-    uint32_t ref = 0;                             // root node
-    for (;;) {
-        while (!(ref & RVB_BVH_LEAF)) {
-            const float4 * n = reinterpret_cast<const float4 *>(sc.nodes + ref) + 2 * c;
-            const float4 a = n[0], b = n[1];
-            const float limit = best_t * (1.0f + sc.cull_rel) + sc.cull_abs;
-            float tn;
-            const bool ok = slab(a, b, o, ix, iy, iz, limit, sc.cull_abs, tn);
-            const uint32_t cref = __float_as_uint(b.z);
-            const uint32_t hits = quad_ballot(ok);
-            if (hits == 0) {
-                if (sp > 0) { --sp; ref = stack[sp * QUADS_PER_BLOCK]; } else ref = NONE;
-                continue;
-            }
-            uint32_t winner;
-            if (ANY) {
-                winner = __ffs(hits) - 1;         // any-hit does not care about visiting order
-            } else {
-                const float key = ok ? tn : __builtin_inff();
-                const float k1 = fminf(key, dpp_f<QP_SWAP1>(key));
-                const float kmin = fminf(k1, dpp_f<QP_SWAP2>(k1));
-                winner = __ffs(quad_ballot(ok && key == kmin)) - 1;   // nearest child first
-            }
-            const uint32_t rest = hits & ~(1u << winner);
-            if (ok && c != winner)
-                stack[(sp + __popc(rest & ((1u << c) - 1u))) * QUADS_PER_BLOCK] = cref;
-            sp += __popc(rest);
-            const uint32_t r0 = quad_bcast_u<0>(cref), r1 = quad_bcast_u<1>(cref), r2 = quad_bcast_u<2>(cref), r3 = quad_bcast_u<3>(cref);
-            ref = winner == 0 ? r0 : winner == 1 ? r1 : winner == 2 ? r2 : r3;
-        }
-        if (ref == NONE)
-            break;
-        const uint32_t first = ref & 0x0FFFFFFFu;
-        const uint32_t count = ((ref >> 28) & 7u) + 1u;
-        float dist = 0.0f;
-        uint32_t idx = NONE;
-        if (c < count) {
-            const float4 * tp = reinterpret_cast<const float4 *>(sc.tris + first + c);
-            const float4 ta = tp[0], tb = tp[1], tc = tp[2];
-            dist = mt_intersect(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), o, d);
-            idx = __float_as_uint(tc.y);
-        }
-        if (ANY) {
-            if (quad_ballot(c < count && dist > RVB_EPSILON && dist <= tmax) != 0)
-                return true;
-        } else {
-            // kernel.cpp:180-188 — smallest distance wins, equal distances go to the lower index.
-            // Lexicographic (distance, index) minimum over the quad's valid lanes.
-            const bool valid = c < count && dist > RVB_EPSILON;
-            float rd = valid ? dist : __builtin_inff();
-            uint32_t ri = valid ? idx : NONE;
-            {
-                const float od = dpp_f<QP_SWAP1>(rd);
-                const uint32_t oi = dpp_u<QP_SWAP1>(ri);
-                if (od < rd || (od == rd && oi < ri)) { rd = od; ri = oi; }
-            }
-            {
-                const float od = dpp_f<QP_SWAP2>(rd);
-                const uint32_t oi = dpp_u<QP_SWAP2>(ri);
-                if (od < rd || (od == rd && oi < ri)) { rd = od; ri = oi; }
-            }
-            if (ri != NONE && (best_i == NONE || rd < best_t || (rd == best_t && ri < best_i))) {
-                best_t = rd;
-                best_i = ri;
-            }
-        }
-        if (sp > 0) { --sp; ref = stack[sp * QUADS_PER_BLOCK]; } else break;
-    }
-    if (ANY)
-        return false;
-    hit.t = best_t;
-    hit.tri = best_i;
-    return best_i != NONE;
+    OneShotJob job = {o, d, tmax, true, false, {0.0f, NONE}};
+    traverse_jobs<ANY>(sc, stack, job);
+    hit = job.result;
+    return job.hit;
 }
 
 // One-lane-per-query traversal (image_kernel): same tests, same rule, the lane walks all four
@@ -163,6 +296,8 @@ __device__ __forceinline__ bool traverse_lane(const SceneDev & sc, const v3 o, c
                                               uint32_t * __restrict__ stack, Hit & hit)
 {
     const float ix = clamp_inv(d.x), iy = clamp_inv(d.y), iz = clamp_inv(d.z);
+    const float oix = o.x * ix, oiy = o.y * iy, oiz = o.z * iz;
+    const float neg_cull = -sc.cull_abs, cull_scale = 1.0f + sc.cull_rel;
     float best_t = ANY ? tmax : __builtin_inff();
     uint32_t best_i = NONE;
     int sp = 0;
@@ -170,14 +305,14 @@ __device__ __forceinline__ bool traverse_lane(const SceneDev & sc, const v3 o, c
     for (;;) {
         while (!(ref & RVB_BVH_LEAF)) {
             const float4 * n = reinterpret_cast<const float4 *>(sc.nodes + ref);
-            const float limit = best_t * (1.0f + sc.cull_rel) + sc.cull_abs;
+            const float limit = fmaf(best_t, cull_scale, sc.cull_abs);
             float key[4];
             uint32_t cref[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const float4 a = n[2 * c], b = n[2 * c + 1];
                 float tn;
-                const bool ok = slab(a, b, o, ix, iy, iz, limit, sc.cull_abs, tn);
+                const bool ok = slab(a, b, ix, iy, iz, oix, oiy, oiz, limit, neg_cull, tn);
                 key[c] = ok ? tn : __builtin_inff();
                 cref[c] = ok ? __float_as_uint(b.z) : NONE;
             }
@@ -232,30 +367,34 @@ __device__ __forceinline__ v3 ld3(const float * p) { return mk3(p[0], p[1], p[2]
 //   chunk 2    intersection.xyz, DIFF = |dot(normal, dir)|         (kernel.cpp:459, :478)
 //   chunk 3    newDist, surface index, triangle index, 1 = valid   (kernel.cpp:460)
 // shadow_kernel turns it into the final Impulse in place.
-__global__ __launch_bounds__(WAVE) void path_kernel(TraceArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t stack_lds[];   // [stack_entries][QUADS_PER_BLOCK]
-    const uint32_t c = threadIdx.x & 3u;
-    const uint32_t q = threadIdx.x >> 2;
-    const uint64_t ray = (uint64_t) blockIdx.x * QUADS_PER_BLOCK + q;
-    if (ray >= a.nrays)
-        return;                                   // whole quads leave together
-    uint32_t * stack = stack_lds + q;
-
-    const float4 d4 = a.directions[ray];
-    v3 o = ld3(a.source);
-    v3 d = mk3(d4.x, d4.y, d4.z);
-    float distance = 0.0f;
+// One ray's bounce chain as a Job: next() hands out the current ray, done() shades the hit
+// (kernel.cpp:459-461, :478), stores the work record and reflects (kernel.cpp:492-501).
+struct PathJob {
+    const TraceArgs & a;
+    uint64_t ray;
+    uint32_t c;
+    v3 o, d;
+    float distance;
     float vol[8];
-#pragma unroll
-    for (int b = 0; b < 8; ++b) vol[b] = 1.0f;
+    uint32_t index;
+    bool alive;
+    float4 * out;
 
-    float4 * out = reinterpret_cast<float4 *>(a.impulses + ray * a.nreflections);
-    uint32_t index = 0;
-    for (; index < a.nreflections; ++index) {
-        Hit h;
-        if (!traverse_quad<false>(a.scene, o, d, 0.0f, stack, h))
-            break;                                                   // kernel.cpp:372-375
+    __device__ __forceinline__ bool next(v3 & o_, v3 & d_, float & tmax)
+    {
+        if (!alive || index >= a.nreflections)
+            return false;
+        o_ = o;
+        d_ = d;
+        tmax = 0.0f;
+        return true;
+    }
+    __device__ __forceinline__ void done(bool hit, const Hit & h)
+    {
+        if (!hit) {                                                  // kernel.cpp:372-375
+            alive = false;
+            return;
+        }
         const float4 sh = reinterpret_cast<const float4 *>(a.scene.shade)[h.tri];
         const v3 normal = mk3(sh.x, sh.y, sh.z);
         const uint32_t surface = __float_as_uint(sh.w);
@@ -271,15 +410,40 @@ __global__ __launch_bounds__(WAVE) void path_kernel(TraceArgs a)
         else if (c == 1) chunk = make_float4(vol[4], vol[5], vol[6], vol[7]);
         else if (c == 2) chunk = make_float4(p.x, p.y, p.z, diff);
         else chunk = make_float4(new_dist, __uint_as_float(surface), __uint_as_float(h.tri), __uint_as_float(1u));
-        out[4 * index + c] = chunk;
+        store_stream(out + 4 * index + c, chunk);
         if (c == 0 && index < RVB_NUM_IMAGE_SOURCE - 1)
             a.early[ray * (RVB_NUM_IMAGE_SOURCE - 1) + index] = h.tri;
         d = reflect3(normal, d);                                     // kernel.cpp:492-499
         o = p;
         distance = new_dist;
+        ++index;
     }
-    if (c == 0)
-        atomicAdd(a.executed, (unsigned long long) index);
+};
+
+__global__ __launch_bounds__(WAVE) void path_kernel(TraceArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t stack_lds[];   // [stack_entries][QUADS_PER_BLOCK]
+    const uint32_t q = threadIdx.x >> 2;
+    const uint64_t ray = (uint64_t) blockIdx.x * QUADS_PER_BLOCK + q;
+    if (ray >= a.nrays)
+        return;                                   // whole quads leave together
+    const float4 d4 = a.directions[ray];
+    PathJob job = {a, ray, threadIdx.x & 3u, ld3(a.source), mk3(d4.x, d4.y, d4.z), 0.0f,
+                   {1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f}, 0u, true,
+                   reinterpret_cast<float4 *>(a.impulses + ray * a.nreflections)};
+#if RVB_PATH_JOBS
+    traverse_jobs<false>(a.scene, stack_lds + q, job);
+#else
+    v3 o, d;
+    float tmax;
+    while (job.next(o, d, tmax)) {
+        Hit h;
+        const bool hit = traverse_quad<false>(a.scene, o, d, tmax, stack_lds + q, h);
+        job.done(hit, h);
+    }
+#endif
+    if (job.c == 0)
+        atomicAdd(a.executed, (unsigned long long) job.index);
 }
 
 // reference kernel.cpp:243-265 (add_image) for a known-valid slot
@@ -410,34 +574,46 @@ __global__ __launch_bounds__(WAVE) void image_kernel(TraceArgs a)
     a.candidates[at] = cand;
 }
 
-__global__ __launch_bounds__(WAVE) void shadow_kernel(TraceArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t stack_lds[];   // [stack_entries][QUADS_PER_BLOCK]
-    const uint32_t c = threadIdx.x & 3u;
-    const uint32_t q = threadIdx.x >> 2;
-    uint32_t * stack = stack_lds + q;
-    const uint64_t total = a.nrays * (uint64_t) a.nreflections;
-    const v3 mic = ld3(a.mic);
-    // a.air[] for this lane's four bands (lanes 0/1 of the quad finish bands 0-3 / 4-7)
-    const float air0 = a.air[(c & 1u) * 4 + 0], air1 = a.air[(c & 1u) * 4 + 1];
-    const float air2 = a.air[(c & 1u) * 4 + 2], air3 = a.air[(c & 1u) * 4 + 3];
-    for (uint64_t g = (uint64_t) blockIdx.x * QUADS_PER_BLOCK + q; g < total; g += (uint64_t) gridDim.x * QUADS_PER_BLOCK) {
-        float4 * rec = reinterpret_cast<float4 *>(a.impulses + g);
-        const float4 mine = rec[c];               // the quad reads the 64-byte record as one line
-        // chunk 3 = (newDist, surface, triangle, valid); chunk 2 = (intersection, DIFF)
-        const uint32_t valid = quad_bcast_u<3>(__float_as_uint(mine.w));
-        if (valid != 1u)
-            continue;                             // ray had already escaped: slot keeps its zero fill
-        const float new_dist = quad_bcast_f<3>(mine.x);
-        const uint32_t surface = quad_bcast_u<3>(__float_as_uint(mine.y));
-        const v3 p = mk3(quad_bcast_f<2>(mine.x), quad_bcast_f<2>(mine.y), quad_bcast_f<2>(mine.z));
-        const float diff = quad_bcast_f<2>(mine.w);
+// The shadow rays as Jobs: a quad walks the work records g, g + stride, ...; next() loads a record
+// (the quad reads its 64 bytes as one line, lane c = chunk c) and aims at the microphone
+// (kernel.cpp:463-469), done() finishes the Impulse in place (kernel.cpp:471-490).
+struct ShadowJob {
+    const TraceArgs & a;
+    uint32_t c;
+    uint64_t g, stride, total;
+    v3 mic;
+    float air0, air1, air2, air3;        // this lane's four bands (lanes 0/1 finish bands 0-3 / 4-7)
+    float4 * rec;
+    float4 mine;
+    v3 p;
+    float diff, new_dist, mag;
+    uint32_t surface;
 
-        // kernel.cpp:463-469 point_intersection(intersection, mic)
-        const v3 b2p = mic - p;
-        const float mag = length3(b2p);
-        Hit h;
-        const bool visible = !traverse_quad<true>(a.scene, p, normalize3(b2p), mag, stack, h);
+    __device__ __forceinline__ bool next(v3 & o_, v3 & d_, float & tmax)
+    {
+        while (g < total) {
+            rec = reinterpret_cast<float4 *>(a.impulses + g);
+            g += stride;
+            mine = load_stream(rec + c);
+            // chunk 3 = (newDist, surface, triangle, valid); chunk 2 = (intersection, DIFF)
+            if (quad_bcast_u<3>(__float_as_uint(mine.w)) != 1u)
+                continue;                         // ray had already escaped: slot keeps its zero fill
+            new_dist = quad_bcast_f<3>(mine.x);
+            surface = quad_bcast_u<3>(__float_as_uint(mine.y));
+            p = mk3(quad_bcast_f<2>(mine.x), quad_bcast_f<2>(mine.y), quad_bcast_f<2>(mine.z));
+            diff = quad_bcast_f<2>(mine.w);
+            const v3 b2p = mic - p;               // kernel.cpp:282-286
+            mag = length3(b2p);
+            o_ = p;
+            d_ = normalize3(b2p);
+            tmax = mag;
+            return true;
+        }
+        return false;
+    }
+    __device__ __forceinline__ void done(bool blocked, const Hit &)
+    {
+        const bool visible = !blocked;
         const float dist = visible ? new_dist + mag : 0.0f;          // kernel.cpp:471
         float4 o = make_float4(0, 0, 0, 0);
         if (c < 2) {
@@ -454,8 +630,35 @@ __global__ __launch_bounds__(WAVE) void shadow_kernel(TraceArgs a)
         } else {
             o.x = seconds_per_meter() * dist;                        // kernel.cpp:489
         }
-        rec[c] = o;
+        store_stream(rec + c, o);
     }
+};
+
+__global__ __launch_bounds__(WAVE) void shadow_kernel(TraceArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t stack_lds[];   // [stack_entries][QUADS_PER_BLOCK]
+    const uint32_t c = threadIdx.x & 3u;
+    const uint32_t q = threadIdx.x >> 2;
+    ShadowJob job = {a};
+    job.c = c;
+    job.g = (uint64_t) blockIdx.x * QUADS_PER_BLOCK + q;
+    job.stride = (uint64_t) gridDim.x * QUADS_PER_BLOCK;
+    job.total = a.nrays * (uint64_t) a.nreflections;
+    job.mic = ld3(a.mic);
+    job.air0 = a.air[(c & 1u) * 4 + 0]; job.air1 = a.air[(c & 1u) * 4 + 1];
+    job.air2 = a.air[(c & 1u) * 4 + 2]; job.air3 = a.air[(c & 1u) * 4 + 3];
+#if RVB_SHADOW_JOBS
+    traverse_jobs<true>(a.scene, stack_lds + q, job);
+#else
+    // one record per quad per pass: the 16 quads of the wave start and finish a pass together
+    v3 o, d;
+    float tmax;
+    while (job.next(o, d, tmax)) {
+        Hit h;
+        const bool blocked = traverse_quad<true>(a.scene, o, d, tmax, stack_lds + q, h);
+        job.done(blocked, h);
+    }
+#endif
 }
 
 }  // namespace
@@ -479,6 +682,7 @@ void rvb_launch_shadow(const TraceArgs & a, hipStream_t s)
     const uint64_t total = a.nrays * (uint64_t) a.nreflections;
     if (total == 0) return;
     uint64_t blocks = (total + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK;
-    if (blocks > 256u * 256u) blocks = 256u * 256u;   // grid-stride beyond 256 single-wave workgroups per CU
+    static const uint64_t per_cu = getenv("RVB_SHADOW_WG_PER_CU") ? strtoull(getenv("RVB_SHADOW_WG_PER_CU"), nullptr, 10) : 256;
+    if (blocks > 256u * per_cu) blocks = 256u * per_cu;     // single-wave workgroups per CU; records beyond are grid-strided
     hipLaunchKernelGGL(shadow_kernel, dim3((unsigned) blocks), dim3(WAVE), a.stack_entries * QUADS_PER_BLOCK * sizeof(uint32_t), s, a);
 }
