@@ -41,6 +41,8 @@ def parse():
     p.add_argument("--sample-rate", type=float, default=44100.0)
     p.add_argument("--mode", choices=["fast", "exact"], default="fast")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
+    p.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     return p.parse_args()
 
@@ -86,10 +88,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     import torch.distributed as dist
+    if args.share_gpu:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     device = torch.device("cuda", local_rank)

@@ -70,6 +70,7 @@ struct rvb_ctx {
     int which = RVB_IR_ALL;
     DevBuf images, hrtf_table, acc, keys_a, keys_b, vals_a, vals_b, sort_temp, scratch_in, scratch_out, hist;
     uint64_t nimages = 0;
+    std::vector<rvb_impulse> images_host;
 
     hipEvent_t next_event()
     {
@@ -115,6 +116,7 @@ const size_t kSmallCandidateCount = 0;
 const size_t kSmallExecuted = 8;
 const size_t kSmallRange = 16;      // two uint32
 const size_t kSmallMaxTime = 24;    // uint32
+const size_t kSmallTraceRange = 32; // two uint32: time range of the traced diffuse impulses (shadow_kernel)
 const size_t kSmallDirect = 64;     // rvb_impulse
 const size_t kSmallBytes = 128;
 
@@ -307,6 +309,7 @@ int rvb_trace(rvb_ctx * ctx, const float mic[3], const float source[3], uint64_t
     if (imp_bytes) RVB_HIP(ctx, hipMemsetAsync(ctx->impulses.p, 0, imp_bytes, ctx->stream));
     if (early_bytes) RVB_HIP(ctx, hipMemsetAsync(ctx->early.p, 0xFF, early_bytes, ctx->stream));
     RVB_HIP(ctx, hipMemsetAsync(ctx->small.p, 0, kSmallBytes, ctx->stream));
+    RVB_HIP(ctx, hipMemsetAsync(ctx->small.as<char>() + kSmallTraceRange, 0xFF, 4, ctx->stream));
 
     TraceArgs a;
     a.scene = ctx->scene;
@@ -317,6 +320,7 @@ int rvb_trace(rvb_ctx * ctx, const float mic[3], const float source[3], uint64_t
     a.candidate_count = reinterpret_cast<uint32_t *>(ctx->small.as<char>() + kSmallCandidateCount);
     a.direct = reinterpret_cast<rvb_impulse *>(ctx->small.as<char>() + kSmallDirect);
     a.executed = reinterpret_cast<unsigned long long *>(ctx->small.as<char>() + kSmallExecuted);
+    a.time_range = reinterpret_cast<uint32_t *>(ctx->small.as<char>() + kSmallTraceRange);
     a.nrays = nrays;
     a.nreflections = (uint32_t) nreflections;
     a.stack_entries = ctx->stack_need;
@@ -575,6 +579,7 @@ static int configure_common(rvb_ctx * ctx, int which, const rvb_impulse * images
     RVB_HIP(ctx, ctx->images.ensure(nimages * sizeof(rvb_impulse)));
     if (nimages) RVB_HIP(ctx, hipMemcpy(ctx->images.p, images, nimages * sizeof(rvb_impulse), hipMemcpyHostToDevice));
     ctx->nimages = nimages;
+    ctx->images_host.assign(images, images + nimages);
     ctx->which = which;
     ctx->ir_configured = true;
     return RVB_OK;
@@ -622,6 +627,31 @@ int rvb_ir_time_range(rvb_ctx * ctx, float * min_nonzero_time, float * max_time)
     if (!ctx) return RVB_ERR_INVALID;
     if (!ctx->ir_configured) return fail(ctx, RVB_ERR_STATE, "rvb_ir_time_range: rvb_ir_configure_* first");
     RVB_BIND(ctx);
+    if (!ctx->model.hrtf) {
+        // Speaker channels keep the input time (kernel.cpp:530-533), so the range is that of the raw
+        // impulses: the diffuse part was reduced inside shadow_kernel, the few images are scanned here.
+        ctx->reset_timings();
+        uint32_t got[2] = {0xFFFFFFFFu, 0u};
+        if (ctx->which & RVB_IR_DIFFUSE) {
+            RVB_HIP(ctx, hipMemcpyAsync(got, ctx->small.as<char>() + kSmallTraceRange, sizeof(got), hipMemcpyDeviceToHost, ctx->stream));
+            RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        float lo = 0.0f, hi = 0.0f;
+        bool have_lo = got[0] != 0xFFFFFFFFu;
+        if (have_lo) std::memcpy(&lo, &got[0], 4);
+        std::memcpy(&hi, &got[1], 4);
+        if (ctx->which & RVB_IR_IMAGES)
+            for (const rvb_impulse & im : ctx->images_host) {
+                bool nonzero = false;
+                for (int b = 0; b < 8; ++b) nonzero = nonzero || im.volume[b] != 0.0f;
+                if (!nonzero) continue;
+                if (im.time != 0.0f && (!have_lo || im.time < lo)) { lo = im.time; have_lo = true; }
+                if (im.time > hi) hi = im.time;
+            }
+        if (min_nonzero_time) *min_nonzero_time = have_lo ? lo : 0.0f;
+        if (max_time) *max_time = hi;
+        return RVB_OK;
+    }
     uint32_t * range = reinterpret_cast<uint32_t *>(ctx->small.as<char>() + kSmallRange);
     RVB_HIP(ctx, hipMemsetAsync(range, 0xFF, 4, ctx->stream));
     RVB_HIP(ctx, hipMemsetAsync(range + 1, 0, 4, ctx->stream));

@@ -27,6 +27,7 @@ struct TraceArgs {
     uint32_t * candidate_count;
     rvb_impulse * direct;               // slot 0
     unsigned long long * executed;      // bounces executed
+    uint32_t * time_range;              // [2] float bits: min non-zero / max time of non-zero diffuse impulses
     uint64_t nrays;
     uint32_t nreflections;
     uint32_t stack_entries;             // LDS traversal stack entries per lane (BuiltScene::stack_need)

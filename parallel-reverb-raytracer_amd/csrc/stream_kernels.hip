@@ -191,35 +191,63 @@ __global__ __launch_bounds__(256) void time_range_kernel(ModelDev m, const float
 }
 
 // accumulation image: acc[bin][channel][band], float atomics
+__device__ __forceinline__ Group16 make_group16(float mine)
+{
+    Group16 g;
+    const uint32_t lane = threadIdx.x & 63u;
+    const int base = (int) (lane & ~15u);
+    g.mine = mine;
+    g.pos = mk3(__shfl(mine, base + 8), __shfl(mine, base + 9), __shfl(mine, base + 10));
+    g.time = __shfl(mine, base + 12);
+    const unsigned long long mask = __ballot((lane & 15u) < 8u && mine != 0.0f);
+    g.nonzero = ((mask >> base) & 0xFFull) != 0;
+    return g;
+}
+
+__device__ __forceinline__ void histogram_add(const ModelDev & m, const Group16 & g, float predelay, float sample_rate,
+                                              uint64_t nbins, float * __restrict__ acc)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t f = lane & 15u;
+    const uint32_t band = f & 7u;
+    // lanes 8..15 of the group take the band volumes of lanes 0..7: second channel of a pair
+    const float vol = __shfl(g.mine, (int) ((lane & ~15u) + band));
+    if (!g.nonzero)
+        return;
+    int64_t row = 0;
+    if (m.hrtf) row = hrtf_row(m, g.pos);
+    for (uint32_t pair = 0; pair < m.nchannels; pair += 2) {
+        const uint32_t ch = pair + (f >> 3);
+        if (ch >= m.nchannels)
+            continue;
+        float gain;
+        if (m.hrtf) gain = m.table[((uint64_t) ch * (360 * 180 + 1) + (uint64_t) row) * 8 + band];
+        else gain = speaker_gain(m, ch, g.pos);
+        const float t = attenuated_time(m, ch, g.pos, g.time);
+        const uint64_t bin = time_bin(t, predelay, sample_rate);
+        if (bin < nbins)
+            atomicAdd(acc + (bin * m.nchannels + ch) * 8 + band, vol * gain);
+    }
+}
+
 __global__ __launch_bounds__(256) void histogram_fast_kernel(ModelDev m, const float * __restrict__ in, uint64_t n,
                                                              float predelay, float sample_rate, uint64_t nbins,
                                                              float * __restrict__ acc)
 {
     const uint64_t nwords = n * 16;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t f = lane & 15u;
-    const uint32_t band = f & 7u;
-    for (uint64_t w = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; w < ((nwords + 63) & ~63ull);
-         w += (uint64_t) gridDim.x * blockDim.x) {
-        const Group16 g = load_group16(in, w, nwords);
-        // lanes 8..15 of the group take the band volumes of lanes 0..7: second channel of a pair
-        const float vol = __shfl(g.mine, (int) ((lane & ~15u) + band));
-        if (!g.nonzero)
-            continue;
-        int64_t row = 0;
-        if (m.hrtf) row = hrtf_row(m, g.pos);
-        for (uint32_t pair = 0; pair < m.nchannels; pair += 2) {
-            const uint32_t ch = pair + (f >> 3);
-            if (ch >= m.nchannels)
-                continue;
-            float gain;
-            if (m.hrtf) gain = m.table[((uint64_t) ch * (360 * 180 + 1) + (uint64_t) row) * 8 + band];
-            else gain = speaker_gain(m, ch, g.pos);
-            const float t = attenuated_time(m, ch, g.pos, g.time);
-            const uint64_t bin = time_bin(t, predelay, sample_rate);
-            if (bin < nbins)
-                atomicAdd(acc + (bin * m.nchannels + ch) * 8 + band, vol * gain);
-        }
+    const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
+    const uint64_t limit = (nwords + 63) & ~63ull;
+    // four independent 256-byte wave loads in flight per iteration (the loop is wave-uniform)
+    for (uint64_t w = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; w < limit; w += 4 * stride) {
+        const uint64_t w1 = w + stride, w2 = w + 2 * stride, w3 = w + 3 * stride;
+        const float m0 = w < nwords ? __builtin_nontemporal_load(in + w) : 0.0f;
+        const float m1 = w1 < nwords ? __builtin_nontemporal_load(in + w1) : 0.0f;
+        const float m2 = w2 < nwords ? __builtin_nontemporal_load(in + w2) : 0.0f;
+        const float m3 = w3 < nwords ? __builtin_nontemporal_load(in + w3) : 0.0f;
+        histogram_add(m, make_group16(m0), predelay, sample_rate, nbins, acc);
+        if (w1 < limit) histogram_add(m, make_group16(m1), predelay, sample_rate, nbins, acc);
+        if (w2 < limit) histogram_add(m, make_group16(m2), predelay, sample_rate, nbins, acc);
+        if (w3 < limit) histogram_add(m, make_group16(m3), predelay, sample_rate, nbins, acc);
     }
 }
 

@@ -588,6 +588,7 @@ struct ShadowJob {
     v3 p;
     float diff, new_dist, mag;
     uint32_t surface;
+    float tmin, tmax_seen;               // arrival-time range of the non-zero impulses this lane's quad produced
 
     __device__ __forceinline__ bool next(v3 & o_, v3 & d_, float & tmax)
     {
@@ -631,6 +632,14 @@ struct ShadowJob {
             o.x = seconds_per_meter() * dist;                        // kernel.cpp:489
         }
         store_stream(rec + c, o);
+        // inputs of findPredelay / MAX_SAMPLE (rayverb.h:49-74, rayverb.cpp:54-57) for free: an impulse
+        // takes part iff any band is non-zero (kernel.cpp:524)
+        const bool nonzero = quad_ballot(c < 2 && (o.x != 0.0f || o.y != 0.0f || o.z != 0.0f || o.w != 0.0f)) != 0;
+        if (nonzero) {
+            const float t = seconds_per_meter() * dist;
+            if (t != 0.0f) tmin = fminf(tmin, t);
+            tmax_seen = fmaxf(tmax_seen, t);
+        }
     }
 };
 
@@ -647,6 +656,8 @@ __global__ __launch_bounds__(WAVE) void shadow_kernel(TraceArgs a)
     job.mic = ld3(a.mic);
     job.air0 = a.air[(c & 1u) * 4 + 0]; job.air1 = a.air[(c & 1u) * 4 + 1];
     job.air2 = a.air[(c & 1u) * 4 + 2]; job.air3 = a.air[(c & 1u) * 4 + 3];
+    job.tmin = __builtin_inff();
+    job.tmax_seen = 0.0f;
 #if RVB_SHADOW_JOBS
     traverse_jobs<true>(a.scene, stack_lds + q, job);
 #else
@@ -659,6 +670,15 @@ __global__ __launch_bounds__(WAVE) void shadow_kernel(TraceArgs a)
         job.done(blocked, h);
     }
 #endif
+    float tmin = job.tmin, tmax_seen = job.tmax_seen;
+    for (int off = 32; off > 0; off >>= 1) {
+        tmin = fminf(tmin, __shfl_xor(tmin, off));
+        tmax_seen = fmaxf(tmax_seen, __shfl_xor(tmax_seen, off));
+    }
+    if (threadIdx.x == 0) {                       // non-negative floats order like their bit patterns
+        if (tmin != __builtin_inff()) atomicMin(a.time_range + 0, __float_as_uint(tmin));
+        atomicMax(a.time_range + 1, __float_as_uint(tmax_seen));
+    }
 }
 
 }  // namespace
