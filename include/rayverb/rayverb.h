@@ -10,6 +10,10 @@
 #pragma once
 
 #include "clstructs.h"
+#include "filters.h"
+#include "generic_functions.h"
+
+#include "rapidjson/document.h"
 
 #include <algorithm>
 #include <array>
@@ -28,6 +32,11 @@ struct rvb_ctx;
 std::vector<std::vector<float>> flattenImpulses(const std::vector<AttenuatedImpulse> & impulse, float samplerate);
 // ... mapped over channels (rayverb.cpp:28-44).
 std::vector<std::vector<std::vector<float>>> flattenImpulses(const std::vector<std::vector<AttenuatedImpulse>> & impulse, float samplerate);
+
+// Filter every band, mix the bands down per channel, then optionally normalise all channels
+// together, scale, and trim the inaudible tail (reference rayverb.h:36-45, rayverb.cpp:125-149).
+std::vector<std::vector<float>> process(RayverbFiltering::FilterType filtertype, std::vector<std::vector<std::vector<float>>> & data,
+                                        float sr, bool do_normalize, float lo_cutoff, bool do_trim_tail, float volumme_scale);
 
 // Earliest non-zero impulse time over any nesting of vectors (reference rayverb.h:49-74).
 inline float findPredelay(const AttenuatedImpulse & i) { return i.time; }
@@ -148,3 +157,7 @@ public:
 private:
     std::vector<AttenuatedImpulse> attenuate(const cl_float3 & mic_pos, const Speaker & speaker, const std::vector<Impulse> & impulses);
 };
+
+// Read a file and parse it as JSON into `doc`; parse errors are reported through the document
+// (reference rayverb.h:311-314, rayverb.cpp:894-903).
+void attemptJsonParse(const std::string & fname, rapidjson::Document & doc);

@@ -1,0 +1,245 @@
+// filters.cpp — the crossover filters and the post-processing chain (reference rayverb/filters.cpp,
+// rayverb/rayverb.cpp:79-149).  Host-side O(samples) work on a few hundred thousand samples.
+#include "../../include/rayverb/rayverb.h"
+
+#include <cmath>
+#include <fstream>
+#include <iterator>
+#include <memory>
+#include <stdexcept>
+
+using std::vector;
+
+namespace {
+
+const unsigned long KERNEL_LENGTH = 29;       // reference filters.h:124, :139
+
+// sin(pi t) / (pi t)
+double sinc(double t)
+{
+    const double pit = M_PI * t;
+    return std::sin(pit) / pit;
+}
+
+// un-windowed low-pass sinc taps (reference filters.cpp:17-34); cutoff as a fraction of the sample rate
+vector<float> sincKernel(double cutoff, unsigned long length)
+{
+    if (!(length % 2))
+        throw std::runtime_error("Length of sinc filter kernel must be odd.");
+    vector<float> ret(length);
+    for (unsigned long i = 0; i != length; ++i)
+        ret[i] = i == (length - 1) / 2 ? 1.0f : (float) sinc(2 * cutoff * ((double) i - (length - 1) / 2.0));
+    return ret;
+}
+
+vector<float> blackman(unsigned long length)
+{
+    const double a0 = 7938.0 / 18608.0, a1 = 9240.0 / 18608.0, a2 = 1430.0 / 18608.0;
+    vector<float> ret(length);
+    for (unsigned long i = 0; i != length; ++i) {
+        const double offset = i / (length - 1.0);
+        ret[i] = (float) (a0 - a1 * std::cos(2 * M_PI * offset) + a2 * std::cos(4 * M_PI * offset));
+    }
+    return ret;
+}
+
+// windowed, peak-normalised low-pass taps (reference filters.cpp:57-71)
+vector<float> lopassKernel(float sr, float cutoff, unsigned long length)
+{
+    vector<float> window = blackman(length);
+    vector<float> kernel = sincKernel(cutoff / sr, length);
+    for (unsigned long i = 0; i != length; ++i)
+        kernel[i] = window[i] * kernel[i];
+    normalize(kernel);
+    return kernel;
+}
+
+// spectral inversion of the low-pass (reference filters.cpp:75-81)
+vector<float> hipassKernel(float sr, float cutoff, unsigned long length)
+{
+    vector<float> kernel = lopassKernel(sr, cutoff, length);
+    for (float & i : kernel) i = -i;
+    kernel[(length - 1) / 2] += 1;
+    return kernel;
+}
+
+// Full linear convolution, zero-padded to `out_length`, multiplied by `out_length`: what the
+// reference's FastConvolution::convolve returns, because FFTW's c2r transform is unnormalised
+// (reference filters.h:56-80).
+vector<float> convolveScaled(const vector<float> & a, const vector<float> & b, unsigned long out_length)
+{
+    vector<double> acc(out_length, 0.0);
+    for (size_t i = 0; i < a.size(); ++i) {
+        if (a[i] == 0.0f) continue;
+        for (size_t j = 0; j < b.size() && i + j < out_length; ++j)
+            acc[i + j] += (double) a[i] * b[j];
+    }
+    vector<float> out(out_length);
+    for (unsigned long i = 0; i < out_length; ++i)
+        out[i] = (float) (acc[i] * (double) out_length);
+    return out;
+}
+
+struct Bandpass {
+    virtual ~Bandpass() {}
+    virtual void setParams(float l, float h, float s) = 0;
+    virtual void filter(vector<float> & data) = 0;
+};
+
+// reference filters.cpp:118-154
+struct BandpassWindowedSinc : Bandpass {
+    vector<float> kernel;
+    void setParams(float l, float h, float s)
+    {
+        vector<float> lop = lopassKernel(s, h, 1 + KERNEL_LENGTH / 2);
+        vector<float> hip = hipassKernel(s, l, 1 + KERNEL_LENGTH / 2);
+        kernel = convolveScaled(lop, hip, KERNEL_LENGTH);
+    }
+    void filter(vector<float> & data) { data = convolveScaled(kernel, data, KERNEL_LENGTH + data.size() - 1); }
+};
+
+// RBJ cookbook band-pass (reference filters.cpp:198-223)
+struct OnepassBandpassBiquad : Bandpass, RayverbFiltering::Biquad {
+    void setParams(float lo, float hi, float sr)
+    {
+        const double c = std::sqrt(lo * hi);
+        const double omega = 2 * M_PI * c / sr;
+        const double cs = std::cos(omega);
+        const double sn = std::sin(omega);
+        const double bandwidth = std::log2(hi / lo);
+        const double Q = sn / (std::log(2) * bandwidth * omega);
+        const double alpha = sn * std::sinh(1 / (2 * Q));
+        const double nrm = 1 / (1 + alpha);
+        Biquad::setParams(nrm * alpha, nrm * 0, nrm * -alpha, nrm * (-2 * cs), nrm * (1 - alpha));
+    }
+    void filter(vector<float> & data) { onepass(data); }
+};
+
+struct TwopassBandpassBiquad : OnepassBandpassBiquad {
+    void filter(vector<float> & data) { twopass(data); }
+};
+
+double getC(double co, double sr)
+{
+    const double wcT = M_PI * co / sr;
+    return std::cos(wcT) / std::sin(wcT);
+}
+
+// zero-phase second-order Butterworth low-pass + high-pass (reference filters.cpp:241-266)
+struct LinkwitzRiley : Bandpass {
+    RayverbFiltering::Biquad lopass, hipass;
+    void setParams(float l, float h, float s)
+    {
+        {
+            const double c = getC(h, s);
+            const double a0 = c * c + c * std::sqrt(2) + 1;
+            lopass.setParams(1 / a0, 2 / a0, 1 / a0, (-2 * (c * c - 1)) / a0, (c * c - c * std::sqrt(2) + 1) / a0);
+        }
+        {
+            const double c = getC(l, s);
+            const double a0 = c * c + c * std::sqrt(2) + 1;
+            hipass.setParams((c * c) / a0, (-2 * c * c) / a0, (c * c) / a0, (-2 * (c * c - 1)) / a0, (c * c - c * std::sqrt(2) + 1) / a0);
+        }
+    }
+    void filter(vector<float> & data)
+    {
+        lopass.twopass(data);
+        hipass.twopass(data);
+    }
+};
+
+}  // namespace
+
+void RayverbFiltering::Biquad::setParams(double _b0, double _b1, double _b2, double _a1, double _a2)
+{
+    b0 = _b0; b1 = _b1; b2 = _b2; a1 = _a1; a2 = _a2;
+}
+
+void RayverbFiltering::Biquad::onepass(vector<float> & data)
+{
+    double z1 = 0, z2 = 0;
+    for (float & i : data) {
+        const double out = i * b0 + z1;
+        z1 = i * b1 + z2 - a1 * out;
+        z2 = i * b2 - a2 * out;
+        i = (float) out;
+    }
+}
+
+void RayverbFiltering::Biquad::twopass(vector<float> & data)
+{
+    onepass(data);
+    std::reverse(data.begin(), data.end());
+    onepass(data);
+    std::reverse(data.begin(), data.end());
+}
+
+void RayverbFiltering::filter(FilterType ft, vector<vector<vector<float>>> & data, float sr, float lo_cutoff)
+{
+    std::unique_ptr<Bandpass> bp;
+    switch (ft) {
+    case FILTER_TYPE_WINDOWED_SINC: bp.reset(new BandpassWindowedSinc()); break;
+    case FILTER_TYPE_BIQUAD_ONEPASS: bp.reset(new OnepassBandpassBiquad()); break;
+    case FILTER_TYPE_BIQUAD_TWOPASS: bp.reset(new TwopassBandpassBiquad()); break;
+    case FILTER_TYPE_LINKWITZ_RILEY: bp.reset(new LinkwitzRiley()); break;
+    }
+    const float EDGES[9] = {lo_cutoff, 175, 350, 700, 1400, 2800, 5600, 11200, 20000};
+    for (auto & channel : data)
+        for (size_t i = 0; i != channel.size() && i < 8; ++i) {
+            bp->setParams(EDGES[i], EDGES[i + 1], sr);
+            bp->filter(channel[i]);
+        }
+}
+
+// ---- mixdown / trim / process (reference rayverb.cpp:79-149) -------------------------------------------
+
+namespace {
+
+vector<float> mixdown(const vector<vector<float>> & data)
+{
+    vector<float> ret(data.front().size(), 0);
+    for (const auto & band : data)
+        for (size_t i = 0; i < ret.size() && i < band.size(); ++i)
+            ret[i] = ret[i] + band[i];
+    return ret;
+}
+
+// Keeps samples up to, NOT including, the last one whose magnitude reaches minVol
+// (the reference drops that sample too — quirk Q8, rayverb.cpp:96-122).
+void trimTail(vector<vector<float>> & audioChannels, float minVol)
+{
+    long len = 0;
+    for (const auto & ch : audioChannels) {
+        long last = -1;
+        for (long i = (long) ch.size() - 1; i >= 0; --i)
+            if (std::fabs(ch[(size_t) i]) >= minVol) { last = i; break; }
+        len = std::max(len, last);       // distance(begin, found.base()) - 1
+    }
+    for (auto & ch : audioChannels)
+        ch.resize((size_t) len);
+}
+
+}  // namespace
+
+vector<vector<float>> process(RayverbFiltering::FilterType filtertype, vector<vector<vector<float>>> & data, float sr,
+                              bool do_normalize, float lo_cutoff, bool do_trim_tail, float volume_scale)
+{
+    RayverbFiltering::filter(filtertype, data, sr, lo_cutoff);
+    vector<vector<float>> ret(data.size());
+    for (size_t i = 0; i < data.size(); ++i)
+        ret[i] = mixdown(data[i]);
+    if (do_normalize)
+        normalize(ret);
+    if (volume_scale != 1)
+        mul(ret, volume_scale);
+    if (do_trim_tail)
+        trimTail(ret, 0.00001);
+    return ret;
+}
+
+void attemptJsonParse(const std::string & fname, rapidjson::Document & doc)
+{
+    std::ifstream in(fname);
+    std::string file((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    doc.Parse(file.c_str());
+}
