@@ -18,7 +18,7 @@ def _build():
     os.makedirs(os.path.dirname(BIN), exist_ok=True)
     assets = os.path.join(ROOT, "tests", "golden", "assets")
     subprocess.check_call([
-        "g++", "-std=c++11", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include"),
+        "g++", "-std=c++11", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "include", "shims"),
         '-DTEST_OBJ="%s"' % os.path.join(assets, "large_square.obj"), '-DTEST_MAT="%s"' % os.path.join(assets, "mat.json"),
         os.path.join(ROOT, "tests", "cpp", "test_rayverb_api.cpp"), "-o", BIN,
         "-L" + PKG, "-lrayverb", "-lrvb_hip", "-Wl,-rpath," + PKG])
