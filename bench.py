@@ -53,18 +53,7 @@ def cpu_baseline(scene, mic, src, nrefl, target_seconds):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle
     oracle = pyoracle.Oracle("port")
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        pass
-    try:                                              # a container's CPU share (cgroup v2 quota)
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            cores = max(1, min(cores, int(int(quota) / int(period))))
-    except (OSError, ValueError):
-        pass
-    cores = min(cores, int(os.environ.get("RVB_CPU_THREADS", "16")))   # the GPU box's CPU share per GPU
+    cores = pyoracle.cpu_threads()
     rays, spent, done = 32, 0.0, 0
     while True:
         dirs = scenes.sphere_directions(rays, seed=1, first=done)

@@ -37,6 +37,23 @@ def _f8(v):
     return (ctypes.c_float * 8)(*[float(x) for x in v])
 
 
+def cpu_threads(cap=16):
+    """Threads worth starting: CPU affinity, clipped by a cgroup-v2 quota and by `cap` (a GPU box gives
+    one GPU's share of the host, 16 cores, while reporting all of them)."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("RVB_CPU_THREADS", str(cap)))))
+
+
 def have_ref():
     return os.path.exists(REF_SO)
 
@@ -71,7 +88,7 @@ class Oracle:
                 _ptr(surfaces), _f3(mic), _f3(source), _u64(nreflections), _f8(air),
                 _ptr(impulses), _ptr(image), _ptr(index)]
         if self.kind == "port":
-            self.lib.rvbo_raytrace(*args, ctypes.c_int(nthreads))
+            self.lib.rvbo_raytrace(*args, ctypes.c_int(nthreads if nthreads > 0 else cpu_threads()))
         else:
             self.lib.rvb_ref_raytrace(*args)
         return impulses, image, index
