@@ -9,9 +9,11 @@
 // float result of the triangle test can land slightly outside the true triangle / true distance.
 //
 // HBM layout (all arrays read-only during a trace, resident in L2 / Infinity Cache):
-//   nodes   : BvhNode[],   128 B, 4-wide, breadth-first (top levels contiguous); one 32-byte
-//             record per child so that the four lanes that cooperate on one ray (trace_kernels.hip)
-//             read one contiguous 128-byte line per node visit
+//   nodes   : BvhNode[],    64 B, 4-wide, breadth-first (top levels contiguous); one 16-byte
+//             record per child — box as six binary16 values rounded OUTWARD (lo down, hi up), so the
+//             four lanes that cooperate on one ray (trace_kernels.hip) read one contiguous 64-byte
+//             half line per node visit with a single 16-byte load each.  Boxes only prune, so their
+//             precision does not touch results; halving node bytes halves the L1 (TCP) traffic.
 //   tris    : BvhTri[],     48 B, in leaf order: v0, e0, e1 (edges precomputed), original index
 //   shade   : TriShade[],   16 B, by ORIGINAL triangle index: unit normal + surface index
 //   verts9  : TriCorners[], 48 B, by ORIGINAL triangle index: the three vertices (image-source)
@@ -28,13 +30,11 @@
 #define RVB_BVH_MAX_LEAF 4
 #define RVB_BVH_STACK 64            // per-lane traversal stack entries (LDS)
 
-struct BvhChild {                   // 32 B = two 16-byte loads
-    float lox, loy, loz, hix;
-    float hiy, hiz;
+struct BvhChild {                   // 16 B = one 16-byte load
+    uint16_t lox, loy, loz, hix, hiy, hiz;   // binary16 bit patterns
     uint32_t ref;                   // EMPTY | LEAF|(count-1)<<28|first | node index
-    uint32_t pad;
 };
-struct BvhNode { BvhChild c[4]; };  // 128 B
+struct BvhNode { BvhChild c[4]; };  // 64 B
 
 struct BvhTri {                     // 48 B
     float v0[3];

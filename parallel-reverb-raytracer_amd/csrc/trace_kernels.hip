@@ -14,8 +14,9 @@
 //                  queries: this is where the chip fills up.
 //
 // Quad-cooperative traversal: the four lanes of a quad own the four children of a node (one
-// contiguous 128-byte line per visit, two 16-byte loads per lane) and the up-to-four triangles
-// of a leaf; they combine results with DPP quad_perm moves, never through memory.  The per-ray
+// contiguous 64-byte half line per visit, one 16-byte load per lane) and the up-to-four triangles
+// of a leaf; they combine results with DPP quad_perm moves, never through memory.  (Nodes are 64 bytes:
+// binary16 boxes rounded outward, one 16-byte load per lane per visit.)  The per-ray
 // stack lives in LDS, 4 bytes per entry.  Every triangle test is the reference's Möller–Trumbore
 // arithmetic (rvb_math.h); the BVH only prunes, so a query returns the brute-force answer.
 #include "kernels.h"
@@ -92,21 +93,26 @@ __device__ __forceinline__ uint32_t quad_ballot(bool pred)
     return (uint32_t) (m >> (threadIdx.x & 60u)) & 0xFu;
 }
 
-// Slab test of one child box, t = lo*inv - o*inv as one FMA per plane.  Boxes are padded by the
-// builder (BuiltScene::pad) and `limit` carries the cull slack, so the test is conservative with
-// respect to the float triangle test (the FMA form moves a plane by <2e-3 of the padding).
+// Slab test of one child box, t = lo*inv - o*inv as one FMA per plane.  A child record is 16 bytes:
+// six binary16 planes rounded outward by the builder + the child reference.  Boxes are padded
+// (BuiltScene::pad) and `limit` carries the cull slack, so the test is conservative with respect to
+// the float triangle test (the FMA form moves a plane by <2e-3 of the padding).
 // Folded: tn = max(entry, -cull_abs), tf = min(exit, limit); hit iff tn <= tf.  Empty child slots
 // are rejected by their ref (minNum/maxNum would swallow a NaN box: max(NaN, -cull) = -cull).
-__device__ __forceinline__ bool slab(const float4 a, const float4 b, const float ix, const float iy, const float iz,
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ half2_t as_half2(uint32_t u) { return __builtin_bit_cast(half2_t, u); }
+
+__device__ __forceinline__ bool slab(const uint4 n, const float ix, const float iy, const float iz,
                                      const float oix, const float oiy, const float oiz,
                                      const float limit, const float neg_cull, float & tn)
 {
-    const float tx0 = fmaf(a.x, ix, -oix), tx1 = fmaf(a.w, ix, -oix);
-    const float ty0 = fmaf(a.y, iy, -oiy), ty1 = fmaf(b.x, iy, -oiy);
-    const float tz0 = fmaf(a.z, iz, -oiz), tz1 = fmaf(b.y, iz, -oiz);
+    const half2_t h0 = as_half2(n.x), h1 = as_half2(n.y), h2 = as_half2(n.z);   // (lo.x, lo.y) (lo.z, hi.x) (hi.y, hi.z)
+    const float tx0 = fmaf((float) h0.x, ix, -oix), tx1 = fmaf((float) h1.y, ix, -oix);
+    const float ty0 = fmaf((float) h0.y, iy, -oiy), ty1 = fmaf((float) h2.x, iy, -oiy);
+    const float tz0 = fmaf((float) h1.x, iz, -oiz), tz1 = fmaf((float) h2.y, iz, -oiz);
     tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), neg_cull));
     const float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), limit));
-    return tn <= tf && __float_as_uint(b.z) != RVB_BVH_EMPTY;
+    return tn <= tf && n.w != RVB_BVH_EMPTY;
 }
 
 // Closest hit (ANY = false): the brute-force winner of reference kernel.cpp:167-192.
@@ -126,7 +132,7 @@ __device__ __forceinline__ void traverse_jobs(const SceneDev & sc, uint32_t * __
     const uint32_t c = threadIdx.x & 3u;          // the child / leaf triangle this lane owns
     const uint32_t lane_base4 = (threadIdx.x & 60u) << 2;         // ds_bpermute address of the quad's lane 0
     const uint32_t lt_mask = (1u << c) - 1u;
-    const char * node_base = reinterpret_cast<const char *>(sc.nodes) + 32u * c;
+    const char * node_base = reinterpret_cast<const char *>(sc.nodes) + 16u * c;
     const float neg_cull = -sc.cull_abs, cull_scale = 1.0f + sc.cull_rel;
     v3 o = mk3(0, 0, 0), d = mk3(0, 0, 0);
     float tmax = 0.0f;
@@ -152,12 +158,11 @@ __device__ __forceinline__ void traverse_jobs(const SceneDev & sc, uint32_t * __
 #if RVB_STAMPS
             st.quad_node_steps += (threadIdx.x & 3u) == 0 ? 1 : 0;
 #endif
-            const float4 * n = reinterpret_cast<const float4 *>(node_base + ((size_t) ref << 7));
-            const float4 a = n[0], b = n[1];
+            const uint4 n = *reinterpret_cast<const uint4 *>(node_base + ((size_t) ref << 6));
             const float limit = fmaf(best_t, cull_scale, sc.cull_abs);
             float tn;
-            const bool ok = slab(a, b, ix, iy, iz, oix, oiy, oiz, limit, neg_cull, tn);
-            const uint32_t cref = __float_as_uint(b.z);
+            const bool ok = slab(n, ix, iy, iz, oix, oiy, oiz, limit, neg_cull, tn);
+            const uint32_t cref = n.w;
             // key = entry distance (two mantissa bits traded for the lane id): the quad minimum names
             // the nearest hit child and the lane that owns it in two DPP steps
             uint32_t key = ok ? ((__float_as_uint(fmaxf(tn, 0.0f)) & ~3u) | c) : NONE;
@@ -304,17 +309,17 @@ __device__ __forceinline__ bool traverse_lane(const SceneDev & sc, const v3 o, c
     uint32_t ref = 0;
     for (;;) {
         while (!(ref & RVB_BVH_LEAF)) {
-            const float4 * n = reinterpret_cast<const float4 *>(sc.nodes + ref);
+            const uint4 * n = reinterpret_cast<const uint4 *>(sc.nodes + ref);
             const float limit = fmaf(best_t, cull_scale, sc.cull_abs);
             float key[4];
             uint32_t cref[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const float4 a = n[2 * c], b = n[2 * c + 1];
+                const uint4 nc = n[c];
                 float tn;
-                const bool ok = slab(a, b, ix, iy, iz, oix, oiy, oiz, limit, neg_cull, tn);
+                const bool ok = slab(nc, ix, iy, iz, oix, oiy, oiz, limit, neg_cull, tn);
                 key[c] = ok ? tn : __builtin_inff();
-                cref[c] = ok ? __float_as_uint(b.z) : NONE;
+                cref[c] = ok ? nc.w : NONE;
             }
 #define RVB_CSWAP(a, b) { if (key[b] < key[a]) { float tk = key[a]; key[a] = key[b]; key[b] = tk; uint32_t tr = cref[a]; cref[a] = cref[b]; cref[b] = tr; } }
             if (!ANY) {
