@@ -157,17 +157,26 @@ def main():
         trace_ms = sum(avg.get(k, 0.0) for k in ("path_kernel", "image_kernel", "shadow_kernel"))
         dominant = max(avg, key=avg.get)
         ach = algorithmic.get(dominant, 0.0) / (avg[dominant] * 1e-3) / 1e9
+        # HBM traffic per launch from the committed PMC passes of this same command (profiles/), if the workload matches
+        traffic = {}
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_n1.json")))
+            if (nrays, nrefl, args.triangles, world) == (100000, 128, 75000, 1):
+                traffic = {k: v["hbm_bytes_per_launch"] for k, v in pmc["kernels"].items()}
+        except (OSError, ValueError, KeyError):
+            pass
         roofline = {"kernel": dominant, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic.get(dominant),
+                    "traffic_source": "profiles/r01_pmc_traffic_n1.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)" if traffic else None,
                     "avg_launch_ms": avg[dominant],
                     "note": "trace kernels are latency/VALU-bound by construction (scene + BVH are cache-resident); "
                             "the HBM-bound kernels of the path are reported in roofline_stream"}
         stream = {}
-        for k in ("time_range_kernel", "histogram_fast_kernel"):
+        for k in ("shadow_kernel", "time_range_kernel", "histogram_fast_kernel"):
             if k in avg and avg[k] > 0:
                 a = algorithmic[k] / (avg[k] * 1e-3) / 1e9
                 stream[k] = {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
-                             "avg_launch_ms": avg[k]}
+                             "avg_launch_ms": avg[k], "traffic": traffic.get(k)}
         out = {
             "metric": "ray_bounces_per_sec", "value": value, "unit": "ray-bounces/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
