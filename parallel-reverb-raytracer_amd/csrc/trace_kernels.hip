@@ -425,7 +425,7 @@ struct PathJob {
     }
 };
 
-__global__ __launch_bounds__(WAVE) void path_kernel(TraceArgs a)
+__global__ __launch_bounds__(WAVE, 7) void path_kernel(TraceArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t stack_lds[];   // [stack_entries][QUADS_PER_BLOCK]
     const uint32_t q = threadIdx.x >> 2;
@@ -648,7 +648,7 @@ struct ShadowJob {
     }
 };
 
-__global__ __launch_bounds__(WAVE) void shadow_kernel(TraceArgs a)
+__global__ __launch_bounds__(WAVE, 7) void shadow_kernel(TraceArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t stack_lds[];   // [stack_entries][QUADS_PER_BLOCK]
     const uint32_t c = threadIdx.x & 3u;
