@@ -53,6 +53,7 @@ struct BuiltScene {
     std::vector<BvhTri> tris;
     std::vector<TriShade> shade;
     std::vector<TriCorners> corners;
+    std::vector<uint32_t> leafpos;  // by ORIGINAL triangle index: position in `tris` (spatially coherent), 0xFFFFFFFF if dropped
     uint32_t depth = 0;             // levels of 4-wide nodes
     uint32_t stack_need = 0;        // worst-case traversal stack entries (<= RVB_BVH_STACK)
     float pad = 0.0f;               // box padding actually used (metres)

@@ -367,6 +367,9 @@ std::string rvb_build_scene(const rvb_triangle * triangles, uint64_t ntriangles,
         out.nodes[it.slot] = node;
     }
     out.depth = max_depth;
+    out.leafpos.assign(ntriangles, 0xFFFFFFFFu);
+    for (uint32_t i = 0; i < nprims; ++i)
+        out.leafpos[out.tris[i].index] = i;
     // Worst-case traversal stack: descending into one child leaves the other children of the
     // node on the stack.  Nodes are breadth-first, so children have larger indices than parents.
     std::vector<uint32_t> need(out.nodes.size(), 0);

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -46,7 +47,7 @@ struct rvb_ctx {
 
     // scene
     bool have_scene = false;
-    DevBuf nodes, tris, shade, corners, surfaces;
+    DevBuf nodes, tris, shade, corners, surfaces, leafpos;
     SceneDev scene;
     uint64_t nnodes = 0, kept = 0;
     uint32_t depth = 0;
@@ -59,7 +60,7 @@ struct rvb_ctx {
     bool traced = false;
     uint64_t nreflections = 0;
     float mic[3] = {0, 0, 0};
-    DevBuf impulses, early, candidates, small, stamps;       // small: [0] candidate count, [2..3] executed, [16..] direct, range
+    DevBuf impulses, early, candidates, small, stamps, sort_keys, sort_scratch, sort_order, group_temp;       // small: [0] candidate count, [2..3] executed, [16..] direct, range
     std::vector<Timing> timings;
     std::vector<hipEvent_t> event_pool;
     size_t events_used = 0;
@@ -178,7 +179,7 @@ void rvb_destroy(rvb_ctx * ctx)
         return;
     (void) hipSetDevice(ctx->device);
     if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
-    for (DevBuf * b : {&ctx->nodes, &ctx->tris, &ctx->shade, &ctx->corners, &ctx->surfaces, &ctx->directions_own, &ctx->impulses,
+    for (DevBuf * b : {&ctx->nodes, &ctx->tris, &ctx->shade, &ctx->corners, &ctx->surfaces, &ctx->leafpos, &ctx->sort_keys, &ctx->sort_scratch, &ctx->sort_order, &ctx->group_temp, &ctx->directions_own, &ctx->impulses,
                        &ctx->early, &ctx->candidates, &ctx->small, &ctx->stamps, &ctx->images, &ctx->hrtf_table, &ctx->acc, &ctx->keys_a,
                        &ctx->keys_b, &ctx->vals_a, &ctx->vals_b, &ctx->sort_temp, &ctx->scratch_in, &ctx->scratch_out, &ctx->hist})
         b->release();
@@ -237,11 +238,14 @@ int rvb_set_scene(rvb_ctx * ctx, const rvb_triangle * triangles, uint64_t ntrian
     RVB_HIP(ctx, upload(ctx->shade, built.shade.data(), built.shade.size() * sizeof(TriShade)));
     RVB_HIP(ctx, upload(ctx->corners, built.corners.data(), built.corners.size() * sizeof(TriCorners)));
     RVB_HIP(ctx, upload(ctx->surfaces, surfaces, nsurfaces * sizeof(rvb_surface)));
+    RVB_HIP(ctx, upload(ctx->leafpos, built.leafpos.data(), built.leafpos.size() * sizeof(uint32_t)));
     ctx->scene.nodes = ctx->nodes.as<const BvhNode>();
     ctx->scene.tris = ctx->tris.as<const BvhTri>();
     ctx->scene.shade = ctx->shade.as<const TriShade>();
     ctx->scene.corners = ctx->corners.as<const TriCorners>();
     ctx->scene.surfaces = ctx->surfaces.as<const rvb_surface>();
+    ctx->scene.leafpos = ctx->leafpos.as<const uint32_t>();
+    ctx->scene.ntris = (uint32_t) built.tris.size();
     // cull slack along the ray: the float distance of a triangle may differ from the exact one
     ctx->scene.cull_abs = built.pad;
     ctx->scene.cull_rel = 1e-4f;
@@ -321,6 +325,25 @@ int rvb_trace(rvb_ctx * ctx, const float mic[3], const float source[3], uint64_t
     a.direct = reinterpret_cast<rvb_impulse *>(ctx->small.as<char>() + kSmallDirect);
     a.executed = reinterpret_cast<unsigned long long *>(ctx->small.as<char>() + kSmallExecuted);
     a.time_range = reinterpret_cast<uint32_t *>(ctx->small.as<char>() + kSmallTraceRange);
+    // record bucketing for coherent shadow rays (RVB_SHADOW_SORT=0 turns it off)
+    static const bool sort_records = !(getenv("RVB_SHADOW_SORT") && getenv("RVB_SHADOW_SORT")[0] == '0');
+    const uint64_t nrecords = nrays * nreflections;
+    a.sort_keys = nullptr; a.sort_order = nullptr;
+    int key_bits = 1;
+    while (key_bits < 32 && (1ull << key_bits) < ctx->scene.ntris) ++key_bits;
+    static const int group_bits = getenv("RVB_SHADOW_SORT_BITS") ? atoi(getenv("RVB_SHADOW_SORT_BITS")) : 32;
+    if (sort_records && nrecords && nrecords < (1ull << 32) && ctx->scene.ntris) {
+        RVB_HIP(ctx, ctx->sort_keys.ensure(nrecords * 4));
+        RVB_HIP(ctx, ctx->sort_scratch.ensure(nrecords * 4));
+        RVB_HIP(ctx, ctx->sort_order.ensure(nrecords * 4));
+        const size_t group_bytes = rvb_group_records_temp_bytes(nrecords);
+        if (group_bytes == 0) return fail(ctx, RVB_ERR_HIP, "rvb_trace: radix sort size query failed");
+        RVB_HIP(ctx, ctx->group_temp.ensure(group_bytes));
+        // records never written (escaped rays) keep key 0xFFFFFFFF: they land in the last bucket and the
+        // shadow kernel skips them by their valid flag
+        RVB_HIP(ctx, hipMemsetAsync(ctx->sort_keys.p, 0xFF, nrecords * 4, ctx->stream));
+        a.sort_keys = ctx->sort_keys.as<uint32_t>();
+    }
     a.nrays = nrays;
     a.nreflections = (uint32_t) nreflections;
     a.stack_entries = ctx->stack_need;
@@ -342,6 +365,14 @@ int rvb_trace(rvb_ctx * ctx, const float mic[3], const float source[3], uint64_t
     rvb_launch_images(a, ctx->stream);
     ctx->end_timing();
     a.scene.stamps = ctx->stamps.as<unsigned long long>() + 16;
+    if (a.sort_keys) {
+        ctx->begin_timing("record_sort_kernels");
+        a.sort_order = ctx->sort_order.as<uint32_t>();
+        RVB_HIP(ctx, hipGetLastError());
+        RVB_HIP(ctx, rvb_group_records(ctx->group_temp.p, ctx->group_temp.cap, a.sort_keys, ctx->sort_scratch.as<uint32_t>(), a.sort_order,
+                                       nrecords, std::max(0, key_bits - group_bits), key_bits, ctx->stream));
+        ctx->end_timing();
+    }
     ctx->begin_timing("shadow_kernel");
     rvb_launch_shadow(a, ctx->stream);
     ctx->end_timing();

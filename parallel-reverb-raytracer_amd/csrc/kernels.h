@@ -13,6 +13,8 @@ struct SceneDev {                       // device pointers of the current scene
     const TriShade * shade = nullptr;
     const TriCorners * corners = nullptr;
     const rvb_surface * surfaces = nullptr;
+    const uint32_t * leafpos = nullptr;  // by original triangle index: position in tris[] (spatial order)
+    uint32_t ntris = 0;                  // entries of tris[]
     float cull_abs = 0.0f;              // slack added to the running closest distance when culling
     float cull_rel = 0.0f;
     unsigned long long * stamps = nullptr;   // diagnostic builds only (RVB_STAMPS)
@@ -27,6 +29,8 @@ struct TraceArgs {
     uint32_t * candidate_count;
     rvb_impulse * direct;               // slot 0
     unsigned long long * executed;      // bounces executed
+    uint32_t * sort_keys;               // [nrays * nreflections] leaf position of the triangle hit, 0xFFFFFFFF = no record (or null)
+    uint32_t * sort_order;              // [nrays * nreflections] record indices grouped by bucket
     uint32_t * time_range;              // [2] float bits: min non-zero / max time of non-zero diffuse impulses
     uint64_t nrays;
     uint32_t nreflections;
@@ -45,6 +49,11 @@ void rvb_launch_images(const TraceArgs & a, hipStream_t s);
 // Phase B: one lane per (ray, bounce): diffuse shadow ray to the microphone and the final
 // Impulse (kernel.cpp:463-490).  Overwrites the work records.
 void rvb_launch_shadow(const TraceArgs & a, hipStream_t s);
+// Grouping of the work records by the leaf position of the triangle they start from (stream_kernels.hip):
+// order[] lists the records bucket by bucket and the shadow kernel walks that list.
+size_t rvb_group_records_temp_bytes(uint64_t n);
+hipError_t rvb_group_records(void * temp, size_t temp_bytes, const uint32_t * keys, uint32_t * keys_scratch, uint32_t * order,
+                             uint64_t n, int begin_bit, int end_bit, hipStream_t s);
 
 // ---- streaming kernels (stream_kernels.hip) ---------------------------------------------------
 struct AttenuationModel {

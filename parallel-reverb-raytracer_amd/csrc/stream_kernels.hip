@@ -17,6 +17,7 @@
 #include "rvb_math.h"
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 
 #define WAVE 64
 
@@ -446,4 +447,24 @@ void rvb_sort_pairs(void * temp, size_t temp_bytes, const uint32_t * keys_in, ui
 {
     if (n == 0) return;
     (void) rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, values_in, values_out, (size_t) n, 0, (unsigned) key_bits, s);
+}
+
+// Grouping of the trace's work records by spatial bucket: sort (bucket key, record index) pairs on the
+// key bits [begin_bit, end_bit) only — a one- or two-pass radix sort; values come from a counting iterator.
+size_t rvb_group_records_temp_bytes(uint64_t n)
+{
+    size_t bytes = 0;
+    const hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t *) nullptr, (uint32_t *) nullptr,
+                                                   rocprim::counting_iterator<uint32_t>(0), (uint32_t *) nullptr, (size_t) n, 0, 32,
+                                                   (hipStream_t) 0);
+    (void) hipGetLastError();          // a size query launches nothing; drop whatever state it left behind
+    return e == hipSuccess ? bytes : 0;
+}
+
+hipError_t rvb_group_records(void * temp, size_t temp_bytes, const uint32_t * keys, uint32_t * keys_scratch, uint32_t * order,
+                             uint64_t n, int begin_bit, int end_bit, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    return rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_scratch, rocprim::counting_iterator<uint32_t>(0), order,
+                                     (size_t) n, (unsigned) begin_bit, (unsigned) end_bit, s);
 }

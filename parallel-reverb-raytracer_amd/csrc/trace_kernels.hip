@@ -22,6 +22,7 @@
 #include "kernels.h"
 #include "rvb_math.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 #ifndef RVB_PATH_JOBS
@@ -68,9 +69,11 @@ __device__ __forceinline__ float4 load_stream(const float4 * p)
     return make_float4(t.x, t.y, t.z, t.w);
 }
 
+// Inverse direction for the (conservative, padded) slab test only — never used by a triangle test,
+// so the 1-ulp hardware reciprocal is enough.
 __device__ __forceinline__ float clamp_inv(float d)
 {
-    float inv = 1.0f / d;                         // +-inf for d == 0
+    float inv = __builtin_amdgcn_rcpf(d);         // +-inf for d == 0
     return fminf(fmaxf(inv, -1e30f), 1e30f);      // keeps 0 * inf out of the slab test
 }
 
@@ -418,6 +421,8 @@ struct PathJob {
         store_stream(out + 4 * index + c, chunk);
         if (c == 0 && index < RVB_NUM_IMAGE_SOURCE - 1)
             a.early[ray * (RVB_NUM_IMAGE_SOURCE - 1) + index] = h.tri;
+        if (c == 1 && a.sort_keys)
+            a.sort_keys[ray * a.nreflections + index] = a.scene.leafpos[h.tri];
         d = reflect3(normal, d);                                     // kernel.cpp:492-499
         o = p;
         distance = new_dist;
@@ -587,7 +592,7 @@ struct ShadowJob {
     uint32_t c;
     uint64_t g, stride, total;
     v3 mic;
-    float air0, air1, air2, air3;        // this lane's four bands (lanes 0/1 finish bands 0-3 / 4-7)
+    float airA, airB;                    // bands 2c, 2c+1: every lane evaluates two of the eight attenuations
     float4 * rec;
     float4 mine;
     v3 p;
@@ -598,7 +603,9 @@ struct ShadowJob {
     __device__ __forceinline__ bool next(v3 & o_, v3 & d_, float & tmax)
     {
         while (g < total) {
-            rec = reinterpret_cast<float4 *>(a.impulses + g);
+            // with a.sort_order the quads of a wave take consecutive records of one bucket: shadow rays that
+            // start within one triangle and all aim at the microphone walk the same BVH nodes
+            rec = reinterpret_cast<float4 *>(a.impulses + (a.sort_order ? (uint64_t) a.sort_order[g] : g));
             g += stride;
             mine = load_stream(rec + c);
             // chunk 3 = (newDist, surface, triangle, valid); chunk 2 = (intersection, DIFF)
@@ -622,14 +629,22 @@ struct ShadowJob {
         const bool visible = !blocked;
         const float dist = visible ? new_dist + mag : 0.0f;          // kernel.cpp:471
         float4 o = make_float4(0, 0, 0, 0);
+        // attenuation of bands 2c, 2c+1 in this lane; lanes 0/1 then collect bands 0-3 / 4-7 by DPP
+        float eA = 0.0f, eB = 0.0f;
+        if (visible) {
+            eA = air_attenuation(dist, airA) * 1.0f;
+            eB = air_attenuation(dist, airB) * 1.0f;
+        }
+        const float e0 = dpp_f<0xE8>(eA), e1 = dpp_f<0xE8>(eB);     // quad_perm [0,2,2,3]: lane 0 <- 0, lane 1 <- 2
+        const float e2 = dpp_f<0xED>(eA), e3 = dpp_f<0xED>(eB);     // quad_perm [1,3,2,3]: lane 0 <- 1, lane 1 <- 3
         if (c < 2) {
             if (visible) {
                 const float4 dc = reinterpret_cast<const float4 *>(a.scene.surfaces + surface)[2 + c];   // diffuse
                 // kernel.cpp:480-485: newVol * attenuation * diffuse * DIFF, left to right
-                o.x = ((mine.x * (air_attenuation(dist, air0) * 1.0f)) * dc.x) * diff;
-                o.y = ((mine.y * (air_attenuation(dist, air1) * 1.0f)) * dc.y) * diff;
-                o.z = ((mine.z * (air_attenuation(dist, air2) * 1.0f)) * dc.z) * diff;
-                o.w = ((mine.w * (air_attenuation(dist, air3) * 1.0f)) * dc.w) * diff;
+                o.x = ((mine.x * e0) * dc.x) * diff;
+                o.y = ((mine.y * e1) * dc.y) * diff;
+                o.z = ((mine.z * e2) * dc.z) * diff;
+                o.w = ((mine.w * e3) * dc.w) * diff;
             }
         } else if (c == 2) {
             o = make_float4(p.x, p.y, p.z, 0.0f);
@@ -659,8 +674,8 @@ __global__ __launch_bounds__(WAVE, 7) void shadow_kernel(TraceArgs a)
     job.stride = (uint64_t) gridDim.x * QUADS_PER_BLOCK;
     job.total = a.nrays * (uint64_t) a.nreflections;
     job.mic = ld3(a.mic);
-    job.air0 = a.air[(c & 1u) * 4 + 0]; job.air1 = a.air[(c & 1u) * 4 + 1];
-    job.air2 = a.air[(c & 1u) * 4 + 2]; job.air3 = a.air[(c & 1u) * 4 + 3];
+    job.airA = a.air[2 * c];
+    job.airB = a.air[2 * c + 1];
     job.tmin = __builtin_inff();
     job.tmax_seen = 0.0f;
 #if RVB_SHADOW_JOBS
