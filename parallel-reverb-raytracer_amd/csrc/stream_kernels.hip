@@ -23,6 +23,8 @@
 
 namespace {
 
+typedef float nt_float4_t __attribute__((ext_vector_type(4)));
+
 struct ModelDev {
     int hrtf;
     uint32_t nchannels;
@@ -191,76 +193,117 @@ __global__ __launch_bounds__(256) void time_range_kernel(ModelDev m, const float
     }
 }
 
-// accumulation image: acc[bin][channel][band], float atomics
-__device__ __forceinline__ Group16 make_group16(float mine)
-{
-    Group16 g;
-    const uint32_t lane = threadIdx.x & 63u;
-    const int base = (int) (lane & ~15u);
-    g.mine = mine;
-    g.pos = mk3(__shfl(mine, base + 8), __shfl(mine, base + 9), __shfl(mine, base + 10));
-    g.time = __shfl(mine, base + 12);
-    const unsigned long long mask = __ballot((lane & 15u) < 8u && mine != 0.0f);
-    g.nonzero = ((mask >> base) & 0xFFull) != 0;
-    return g;
-}
+// accumulation image: acc[bin][channel][band], float atomics.
+// Two phases per 64 impulses of a wave, through LDS:
+//   1. impulse per lane: gain of every channel and the bin — computed ONCE per impulse
+//      (the 16-lanes-per-impulse layout would recompute them in 16 lanes: ~30 wave instructions per
+//      impulse, issue-bound; this form needs ~5);
+//   2. 16 lanes per impulse (8 bands x 2 channels): one float-atomic wave instruction adds
+//      4 impulses x 64 contiguous bytes.
+#define HIST_ROW 20     // LDS words per staged impulse: 16 record words + padding (b128-aligned, 4-way conflicts at most)
+#define HIST_MAXCH 8
 
-__device__ __forceinline__ void histogram_add(const ModelDev & m, const Group16 & g, float predelay, float sample_rate,
-                                              uint64_t nbins, float * __restrict__ acc)
-{
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t f = lane & 15u;
-    const uint32_t band = f & 7u;
-    // lanes 8..15 of the group take the band volumes of lanes 0..7: second channel of a pair
-    const float vol = __shfl(g.mine, (int) ((lane & ~15u) + band));
-    if (!g.nonzero)
-        return;
-    int64_t row = 0;
-    if (m.hrtf) row = hrtf_row(m, g.pos);
-    for (uint32_t pair = 0; pair < m.nchannels; pair += 2) {
-        const uint32_t ch = pair + (f >> 3);
-        if (ch >= m.nchannels)
-            continue;
-        float gain;
-        if (m.hrtf) gain = m.table[((uint64_t) ch * (360 * 180 + 1) + (uint64_t) row) * 8 + band];
-        else gain = speaker_gain(m, ch, g.pos);
-        const float t = attenuated_time(m, ch, g.pos, g.time);
-        const uint64_t bin = time_bin(t, predelay, sample_rate);
-        if (bin < nbins)
-            atomicAdd(acc + (bin * m.nchannels + ch) * 8 + band, vol * gain);
-    }
-}
-
-__global__ __launch_bounds__(256) void histogram_fast_kernel(ModelDev m, const float * __restrict__ in, uint64_t n,
+__global__ __launch_bounds__(256) void histogram_fast_kernel(ModelDev m, const float4 * __restrict__ in, uint64_t n,
                                                              float predelay, float sample_rate, uint64_t nbins,
                                                              float * __restrict__ acc)
 {
-    const uint64_t nwords = n * 16;
-    const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
-    const uint64_t limit = (nwords + 63) & ~63ull;
-    // four independent 256-byte wave loads in flight per iteration (the loop is wave-uniform)
-    for (uint64_t w = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; w < limit; w += 4 * stride) {
-        const uint64_t w1 = w + stride, w2 = w + 2 * stride, w3 = w + 3 * stride;
-        const float m0 = w < nwords ? __builtin_nontemporal_load(in + w) : 0.0f;
-        const float m1 = w1 < nwords ? __builtin_nontemporal_load(in + w1) : 0.0f;
-        const float m2 = w2 < nwords ? __builtin_nontemporal_load(in + w2) : 0.0f;
-        const float m3 = w3 < nwords ? __builtin_nontemporal_load(in + w3) : 0.0f;
-        histogram_add(m, make_group16(m0), predelay, sample_rate, nbins, acc);
-        if (w1 < limit) histogram_add(m, make_group16(m1), predelay, sample_rate, nbins, acc);
-        if (w2 < limit) histogram_add(m, make_group16(m2), predelay, sample_rate, nbins, acc);
-        if (w3 < limit) histogram_add(m, make_group16(m3), predelay, sample_rate, nbins, acc);
+    __shared__ __attribute__((aligned(16))) float stage[4][64 * HIST_ROW];      // the wave's 64 records
+    __shared__ float gains[4][64 * HIST_MAXCH];
+    __shared__ uint32_t bins[4][64 * 2];                                        // speakers: one bin; hrtf: one per ear
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    float * st = stage[wave];
+    float * gn = gains[wave];
+    uint32_t * bn = bins[wave];
+    const uint64_t nwaves = (uint64_t) gridDim.x * 4;
+    const uint64_t ngroups = (n + 63) / 64;
+    const uint32_t f = lane & 15u, band = f & 7u, chsel = f >> 3;
+    for (uint64_t grp = (uint64_t) blockIdx.x * 4 + wave; grp < ngroups; grp += nwaves) {
+        const uint64_t first = grp * 64;
+        // stage 64 records (4 KiB) with four fully coalesced 1-KiB wave loads
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint64_t chunk = first * 4 + (uint64_t) k * 64 + lane;        // 16-byte chunk index
+            float4 v = make_float4(0, 0, 0, 0);
+            if (chunk < n * 4) {
+                const nt_float4_t t = __builtin_nontemporal_load(reinterpret_cast<const nt_float4_t *>(in) + chunk);
+                v = make_float4(t.x, t.y, t.z, t.w);
+            }
+            const uint32_t imp = (uint32_t) ((k * 64 + lane) >> 2), part = lane & 3u;
+            *reinterpret_cast<float4 *>(st + imp * HIST_ROW + part * 4) = v;
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0): the wave's own LDS writes (one wave per staging area)
+        __builtin_amdgcn_wave_barrier();
+        // phase 1: lane = impulse
+        {
+            const float4 v0 = *reinterpret_cast<const float4 *>(st + lane * HIST_ROW);
+            const float4 v1 = *reinterpret_cast<const float4 *>(st + lane * HIST_ROW + 4);
+            const float4 p4 = *reinterpret_cast<const float4 *>(st + lane * HIST_ROW + 8);
+            const float time = st[lane * HIST_ROW + 12];
+            const bool nonzero = v0.x != 0.0f || v0.y != 0.0f || v0.z != 0.0f || v0.w != 0.0f
+                              || v1.x != 0.0f || v1.y != 0.0f || v1.z != 0.0f || v1.w != 0.0f;
+            const v3 pos = mk3(p4.x, p4.y, p4.z);
+            uint32_t b0 = 0xFFFFFFFFu, b1 = 0xFFFFFFFFu;                       // 0xFFFFFFFF: contributes nothing
+            if (nonzero && first + lane < n) {
+                if (m.hrtf) {
+                    const int64_t row = hrtf_row(m, pos);
+                    // gains of an hrtf impulse are per band: keep the row, phase 2 reads the table
+                    gn[lane * HIST_MAXCH] = __uint_as_float((uint32_t) row);
+                    b0 = time_bin(hrtf_time(m, 0, pos, time), predelay, sample_rate);
+                    b1 = time_bin(hrtf_time(m, 1, pos, time), predelay, sample_rate);
+                } else {
+                    for (uint32_t ch = 0; ch < m.nchannels; ++ch)
+                        gn[lane * HIST_MAXCH + ch] = speaker_gain(m, ch, pos);
+                    b0 = b1 = time_bin(time, predelay, sample_rate);
+                }
+            }
+            bn[lane * 2] = b0;
+            bn[lane * 2 + 1] = b1;
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        // phase 2: 16 lanes per impulse, 4 impulses per wave instruction
+        for (uint32_t j = 0; j < 16; ++j) {
+            const uint32_t imp = j * 4 + (lane >> 4);
+            const float vol = st[imp * HIST_ROW + band];
+            for (uint32_t pair = 0; pair < m.nchannels; pair += 2) {
+                const uint32_t ch = pair + chsel;
+                if (ch >= m.nchannels)
+                    continue;
+                const uint64_t bin = bn[imp * 2 + (m.hrtf ? ch : 0)];
+                if (bin >= nbins)
+                    continue;                      // zero-volume impulse (or beyond the histogram)
+                float gain;
+                if (m.hrtf) gain = m.table[((uint64_t) ch * (360 * 180 + 1) + (uint64_t) __float_as_uint(gn[imp * HIST_MAXCH])) * 8 + band];
+                else gain = gn[imp * HIST_MAXCH + ch];
+                atomicAdd(acc + (bin * m.nchannels + ch) * 8 + band, vol * gain);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();          // staging area is reused by the next group
     }
 }
 
-// acc[bin][ch][band] -> out[ch][band][bin] (+=, so that several shards / image passes can add up)
+// acc[bin][ch][band] -> out[ch][band][bin] (+=, so that several shards / image passes can add up).
+// 64-bin tiles through LDS: the read is one contiguous span, the writes are 256-byte runs per (ch, band).
+#define TR_BINS 64
 __global__ __launch_bounds__(256) void histogram_transpose_kernel(const float * __restrict__ acc, float * __restrict__ out,
                                                                   uint32_t nchannels, uint64_t nbins)
 {
-    const uint64_t total = nbins * nchannels * 8;
-    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t) gridDim.x * blockDim.x) {
-        const uint64_t bin = i % nbins;
-        const uint64_t cb = i / nbins;          // ch * 8 + band
-        out[i] += acc[bin * nchannels * 8 + cb];
+    __shared__ float tile[64][TR_BINS + 1];                  // [ch*8+band][bin], up to 8 channels
+    const uint32_t cb = nchannels * 8;
+    const uint64_t ntiles = (nbins + TR_BINS - 1) / TR_BINS;
+    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const uint64_t bin0 = t * TR_BINS;
+        const uint32_t count = (uint32_t) min((uint64_t) TR_BINS, nbins - bin0) * cb;
+        for (uint32_t i = threadIdx.x; i < count; i += 256)
+            tile[i % cb][i / cb] = acc[bin0 * cb + i];
+        __syncthreads();
+        const uint32_t width = (uint32_t) min((uint64_t) TR_BINS, nbins - bin0);
+        for (uint32_t i = threadIdx.x; i < cb * TR_BINS; i += 256) {
+            const uint32_t row = i / TR_BINS, col = i % TR_BINS;
+            if (col < width)
+                out[(uint64_t) row * nbins + bin0 + col] += tile[row][col];
+        }
+        __syncthreads();
     }
 }
 
@@ -390,13 +433,13 @@ void rvb_launch_histogram_fast(const AttenuationModel & m, const rvb_impulse * i
                                float sample_rate, uint64_t nbins, float * acc, hipStream_t s)
 {
     if (n == 0) return;
-    hipLaunchKernelGGL(histogram_fast_kernel, dim3(stream_blocks(n * 16, 256)), dim3(256), 0, s, make_model(m),
-                       reinterpret_cast<const float *>(in), n, predelay, sample_rate, nbins, acc);
+    hipLaunchKernelGGL(histogram_fast_kernel, dim3(stream_blocks(n, 256)), dim3(256), 0, s, make_model(m),
+                       reinterpret_cast<const float4 *>(in), n, predelay, sample_rate, nbins, acc);
 }
 
 void rvb_launch_histogram_transpose(const float * acc, float * out, uint32_t nchannels, uint64_t nbins, hipStream_t s)
 {
-    hipLaunchKernelGGL(histogram_transpose_kernel, dim3(stream_blocks(nbins * nchannels * 8, 256)), dim3(256), 0, s,
+    hipLaunchKernelGGL(histogram_transpose_kernel, dim3(stream_blocks((nbins + TR_BINS - 1) / TR_BINS * 256, 256)), dim3(256), 0, s,
                        acc, out, nchannels, nbins);
 }
 
