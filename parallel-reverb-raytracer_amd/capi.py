@@ -183,7 +183,8 @@ class Context:
         count = _u64(0)
         self._check(self.lib.rvb_get_image_candidates(self.handle, None, _u64(0), ctypes.byref(count)))
         out = np.zeros(count.value, dtype=IMAGE_CANDIDATE)
-        self._check(self.lib.rvb_get_image_candidates(self.handle, _ptr(out), _u64(out.shape[0]), ctypes.byref(count)))
+        if count.value:
+            self._check(self.lib.rvb_get_image_candidates(self.handle, _ptr(out), _u64(out.shape[0]), ctypes.byref(count)))
         return out
 
     def get_raw_images(self, remove_direct):

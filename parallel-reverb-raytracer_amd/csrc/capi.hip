@@ -61,6 +61,8 @@ struct rvb_ctx {
     uint64_t nreflections = 0;
     float mic[3] = {0, 0, 0};
     DevBuf impulses, early, candidates, small, stamps, sort_keys, sort_scratch, sort_order, group_temp;       // small: [0] candidate count, [2..3] executed, [16..] direct, range
+    unsigned char small_host[128] = {0};        // host mirror of `small`, fetched once per trace
+    bool small_valid = false;
     std::vector<Timing> timings;
     std::vector<hipEvent_t> event_pool;
     size_t events_used = 0;
@@ -309,8 +311,8 @@ int rvb_trace(rvb_ctx * ctx, const float mic[3], const float source[3], uint64_t
     RVB_HIP(ctx, ctx->early.ensure(early_bytes));
     RVB_HIP(ctx, ctx->candidates.ensure((size_t) nrays * 9 * sizeof(rvb_image_candidate)));
 
-    // reference rayverb.cpp:600-616: outputs start zero-filled
-    if (imp_bytes) RVB_HIP(ctx, hipMemsetAsync(ctx->impulses.p, 0, imp_bytes, ctx->stream));
+    // reference rayverb.cpp:600-616: outputs start zero-filled — path_kernel writes every slot of the
+    // impulse array itself (work record or zeros), so no 819 MB fill is needed here
     if (early_bytes) RVB_HIP(ctx, hipMemsetAsync(ctx->early.p, 0xFF, early_bytes, ctx->stream));
     RVB_HIP(ctx, hipMemsetAsync(ctx->small.p, 0, kSmallBytes, ctx->stream));
     RVB_HIP(ctx, hipMemsetAsync(ctx->small.as<char>() + kSmallTraceRange, 0xFF, 4, ctx->stream));
@@ -339,9 +341,8 @@ int rvb_trace(rvb_ctx * ctx, const float mic[3], const float source[3], uint64_t
         const size_t group_bytes = rvb_group_records_temp_bytes(nrecords);
         if (group_bytes == 0) return fail(ctx, RVB_ERR_HIP, "rvb_trace: radix sort size query failed");
         RVB_HIP(ctx, ctx->group_temp.ensure(group_bytes));
-        // records never written (escaped rays) keep key 0xFFFFFFFF: they land in the last bucket and the
+        // slots of escaped rays get key 0xFFFFFFFF from path_kernel: they land in the last bucket and the
         // shadow kernel skips them by their valid flag
-        RVB_HIP(ctx, hipMemsetAsync(ctx->sort_keys.p, 0xFF, nrecords * 4, ctx->stream));
         a.sort_keys = ctx->sort_keys.as<uint32_t>();
     }
     a.nrays = nrays;
@@ -379,7 +380,19 @@ int rvb_trace(rvb_ctx * ctx, const float mic[3], const float source[3], uint64_t
     RVB_HIP(ctx, hipGetLastError());
     ctx->nreflections = nreflections;
     ctx->traced = true;
+    ctx->small_valid = false;
     ctx->ir_configured = false;
+    return RVB_OK;
+}
+
+// one synchronising 128-byte read per trace serves candidate count, direct path, time range, bounce count
+static int fetch_small(rvb_ctx * ctx)
+{
+    if (ctx->small_valid)
+        return RVB_OK;
+    RVB_HIP(ctx, hipMemcpyAsync(ctx->small_host, ctx->small.p, kSmallBytes, hipMemcpyDeviceToHost, ctx->stream));
+    RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->small_valid = true;
     return RVB_OK;
 }
 
@@ -411,8 +424,9 @@ int rvb_get_direct(rvb_ctx * ctx, rvb_impulse * out)
     if (!ctx || !out) return RVB_ERR_INVALID;
     if (!ctx->traced) return fail(ctx, RVB_ERR_STATE, "rvb_get_direct: nothing traced");
     RVB_BIND(ctx);
-    RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    RVB_HIP(ctx, hipMemcpy(out, ctx->small.as<char>() + kSmallDirect, sizeof(rvb_impulse), hipMemcpyDeviceToHost));
+    int rc = fetch_small(ctx);
+    if (rc != RVB_OK) return rc;
+    std::memcpy(out, ctx->small_host + kSmallDirect, sizeof(rvb_impulse));
     return RVB_OK;
 }
 
@@ -421,9 +435,10 @@ int rvb_get_image_candidates(rvb_ctx * ctx, rvb_image_candidate * out, uint64_t 
     if (!ctx || !count) return RVB_ERR_INVALID;
     if (!ctx->traced) return fail(ctx, RVB_ERR_STATE, "rvb_get_image_candidates: nothing traced");
     RVB_BIND(ctx);
-    RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = fetch_small(ctx);
+    if (rc != RVB_OK) return rc;
     uint32_t n = 0;
-    RVB_HIP(ctx, hipMemcpy(&n, ctx->small.as<char>() + kSmallCandidateCount, sizeof(n), hipMemcpyDeviceToHost));
+    std::memcpy(&n, ctx->small_host + kSmallCandidateCount, sizeof(n));
     *count = n;
     if (!out)
         return RVB_OK;                       // size query
@@ -664,8 +679,9 @@ int rvb_ir_time_range(rvb_ctx * ctx, float * min_nonzero_time, float * max_time)
         ctx->reset_timings();
         uint32_t got[2] = {0xFFFFFFFFu, 0u};
         if (ctx->which & RVB_IR_DIFFUSE) {
-            RVB_HIP(ctx, hipMemcpyAsync(got, ctx->small.as<char>() + kSmallTraceRange, sizeof(got), hipMemcpyDeviceToHost, ctx->stream));
-            RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            int rc = fetch_small(ctx);
+            if (rc != RVB_OK) return rc;
+            std::memcpy(got, ctx->small_host + kSmallTraceRange, sizeof(got));
         }
         float lo = 0.0f, hi = 0.0f;
         bool have_lo = got[0] != 0xFFFFFFFFu;
@@ -821,9 +837,10 @@ int rvb_executed_bounces(rvb_ctx * ctx, uint64_t * bounces)
     if (!ctx || !bounces) return RVB_ERR_INVALID;
     if (!ctx->traced) return fail(ctx, RVB_ERR_STATE, "rvb_executed_bounces: nothing traced");
     RVB_BIND(ctx);
-    RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = fetch_small(ctx);
+    if (rc != RVB_OK) return rc;
     unsigned long long v = 0;
-    RVB_HIP(ctx, hipMemcpy(&v, ctx->small.as<char>() + kSmallExecuted, sizeof(v), hipMemcpyDeviceToHost));
+    std::memcpy(&v, ctx->small_host + kSmallExecuted, sizeof(v));
     *bounces = v;
     return RVB_OK;
 }

@@ -452,6 +452,13 @@ __global__ __launch_bounds__(WAVE, 7) void path_kernel(TraceArgs a)
         job.done(hit, h);
     }
 #endif
+    // An escaped ray leaves its remaining slots zero-filled (reference rayverb.cpp:600-603 zero-fills the
+    // whole buffer before every launch; here only the few slots that need it are written).
+    for (uint32_t i = job.index; i < a.nreflections; ++i) {
+        store_stream(job.out + 4 * i + job.c, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+        if (job.c == 1 && a.sort_keys)
+            a.sort_keys[ray * a.nreflections + i] = NONE;
+    }
     if (job.c == 0)
         atomicAdd(a.executed, (unsigned long long) job.index);
 }
