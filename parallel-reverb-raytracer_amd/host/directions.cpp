@@ -1,4 +1,4 @@
-// helpers.cpp — ray directions (reference rayverb/helpers.cpp:63-81).
+// directions.cpp — ray directions (reference rayverb/helpers.cpp:63-81).
 #include "../../include/rayverb/helpers.h"
 
 #include <chrono>

@@ -1,4 +1,4 @@
-// filters.cpp — the crossover filters and the post-processing chain (reference rayverb/filters.cpp,
+// postprocess.cpp — the crossover filters and the post-processing chain (reference rayverb/filters.cpp,
 // rayverb/rayverb.cpp:79-149).  Host-side O(samples) work on a few hundred thousand samples.
 #include "../../include/rayverb/rayverb.h"
 

@@ -1,4 +1,4 @@
-// rayverb.cpp — the reference's host classes (rayverb/rayverb.h) on top of the rvb C-ABI.
+// rayverb_api.cpp — the reference's host classes (rayverb/rayverb.h) on top of the rvb C-ABI.
 // Every compute step goes through librvb_hip.so (HIP kernels); nothing here computes results on
 // the CPU except the reference's own host-side steps (bounds warnings, vector plumbing).
 #include "../../include/rayverb/rayverb.h"
