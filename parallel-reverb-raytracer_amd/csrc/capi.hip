@@ -40,6 +40,8 @@ struct Timing { std::string name; hipEvent_t start, stop; };
 struct rvb_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side_stream = nullptr;          // image_kernel runs here, beside the record grouping
+    hipEvent_t path_done = nullptr, side_done = nullptr;
     std::string error;
     std::string arch;
     int compute_units = 0;
@@ -84,16 +86,17 @@ struct rvb_ctx {
         }
         return event_pool[events_used++];
     }
-    void begin_timing(const char * name)
+    void begin_timing(const char * name, hipStream_t on = nullptr)
     {
         Timing t;
         t.name = name;
         t.start = next_event();
         t.stop = next_event();
-        (void) hipEventRecord(t.start, stream);
+        (void) hipEventRecord(t.start, on ? on : stream);
         timings.push_back(t);
     }
-    void end_timing() { (void) hipEventRecord(timings.back().stop, stream); }
+    void end_timing(hipStream_t on = nullptr) { (void) hipEventRecord(timings.back().stop, on ? on : stream); }
+    void end_timing_at(size_t index, hipStream_t on) { (void) hipEventRecord(timings[index].stop, on); }
     void reset_timings() { timings.clear(); events_used = 0; }
 };
 
@@ -166,6 +169,9 @@ int rvb_create(rvb_ctx ** out, int device, unsigned flags)
     ctx->compute_units = prop.multiProcessorCount;
     ctx->hbm_bytes = prop.totalGlobalMem;
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->path_done, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->side_done, hipEventDisableTiming)) != hipSuccess ||
         (e = ctx->small.ensure(kSmallBytes)) != hipSuccess) {
         std::string what = std::string("rvb_create: ") + hipGetErrorString(e);
         delete ctx;
@@ -186,6 +192,9 @@ void rvb_destroy(rvb_ctx * ctx)
                        &ctx->keys_b, &ctx->vals_a, &ctx->vals_b, &ctx->sort_temp, &ctx->scratch_in, &ctx->scratch_out, &ctx->hist})
         b->release();
     for (hipEvent_t e : ctx->event_pool) (void) hipEventDestroy(e);
+    if (ctx->path_done) (void) hipEventDestroy(ctx->path_done);
+    if (ctx->side_done) (void) hipEventDestroy(ctx->side_done);
+    if (ctx->side_stream) { (void) hipStreamSynchronize(ctx->side_stream); (void) hipStreamDestroy(ctx->side_stream); }
     if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -361,10 +370,16 @@ int rvb_trace(rvb_ctx * ctx, const float mic[3], const float source[3], uint64_t
     ctx->begin_timing("path_kernel");
     rvb_launch_path(a, ctx->stream);
     ctx->end_timing();
-    ctx->begin_timing("image_kernel");
+    // image_kernel and the record grouping both depend on path_kernel only: the first (latency-bound) runs on the
+    // side stream beside the second (bandwidth-bound); shadow_kernel, which rewrites the records image_kernel
+    // reads, waits for both.
+    RVB_HIP(ctx, hipEventRecord(ctx->path_done, ctx->stream));
+    RVB_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->path_done, 0));
+    ctx->begin_timing("image_kernel", ctx->side_stream);
     a.scene.stamps = nullptr;
-    rvb_launch_images(a, ctx->stream);
-    ctx->end_timing();
+    rvb_launch_images(a, ctx->side_stream);
+    ctx->end_timing(ctx->side_stream);
+    RVB_HIP(ctx, hipEventRecord(ctx->side_done, ctx->side_stream));
     a.scene.stamps = ctx->stamps.as<unsigned long long>() + 16;
     if (a.sort_keys) {
         ctx->begin_timing("record_sort_kernels");
@@ -374,6 +389,7 @@ int rvb_trace(rvb_ctx * ctx, const float mic[3], const float source[3], uint64_t
                                        nrecords, std::max(0, key_bits - group_bits), key_bits, ctx->stream));
         ctx->end_timing();
     }
+    RVB_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_done, 0));
     ctx->begin_timing("shadow_kernel");
     rvb_launch_shadow(a, ctx->stream);
     ctx->end_timing();
