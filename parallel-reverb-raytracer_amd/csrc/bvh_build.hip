@@ -78,7 +78,10 @@ uint16_t to_half_outward(float x, bool down)
     return b;
 }
 
-const int kBins = 16;
+#ifndef RVB_SAH_BINS
+#define RVB_SAH_BINS 16
+#endif
+const int kBins = RVB_SAH_BINS;
 const int kMaxBinaryDepth = 48;
 
 struct Builder {

@@ -54,6 +54,7 @@ struct rvb_ctx {
     uint64_t nnodes = 0, kept = 0;
     uint32_t depth = 0;
     uint32_t stack_need = RVB_BVH_STACK;
+    uint64_t nsurfaces = 0;
 
     // rays + trace results
     DevBuf directions_own;
@@ -264,6 +265,7 @@ int rvb_set_scene(rvb_ctx * ctx, const rvb_triangle * triangles, uint64_t ntrian
     ctx->kept = built.tris.size();
     ctx->depth = built.depth;
     ctx->stack_need = built.stack_need;
+    ctx->nsurfaces = nsurfaces;
     ctx->have_scene = true;
     return RVB_OK;
 }
@@ -342,7 +344,9 @@ int rvb_trace(rvb_ctx * ctx, const float mic[3], const float source[3], uint64_t
     a.sort_keys = nullptr; a.sort_order = nullptr;
     int key_bits = 1;
     while (key_bits < 32 && (1ull << key_bits) < ctx->scene.ntris) ++key_bits;
-    static const int group_bits = getenv("RVB_SHADOW_SORT_BITS") ? atoi(getenv("RVB_SHADOW_SORT_BITS")) : 32;
+    // The grouping only has to bring neighbouring triangles together: the top 16 bits of the leaf position are two
+    // onesweep passes instead of three (C2, 17 key bits: grouping 0.66 -> 0.51 ms beside image_kernel, shadow_kernel +0.02 ms).
+    static const int group_bits = getenv("RVB_SHADOW_SORT_BITS") ? atoi(getenv("RVB_SHADOW_SORT_BITS")) : 16;
     if (sort_records && nrecords && nrecords < (1ull << 32) && ctx->scene.ntris) {
         RVB_HIP(ctx, ctx->sort_keys.ensure(nrecords * 4));
         RVB_HIP(ctx, ctx->sort_scratch.ensure(nrecords * 4));
@@ -357,6 +361,7 @@ int rvb_trace(rvb_ctx * ctx, const float mic[3], const float source[3], uint64_t
     a.nrays = nrays;
     a.nreflections = (uint32_t) nreflections;
     a.stack_entries = ctx->stack_need;
+    a.lds_surfaces = rvb_lds_surfaces(ctx->stack_need, ctx->nsurfaces);
     a.ray_offset = ray_offset;
     for (int i = 0; i < 3; ++i) { a.mic[i] = mic[i]; a.source[i] = source[i]; ctx->mic[i] = mic[i]; }
     for (int i = 0; i < 8; ++i) a.air[i] = air_coefficient[i];

@@ -35,6 +35,7 @@ struct TraceArgs {
     uint64_t nrays;
     uint32_t nreflections;
     uint32_t stack_entries;             // LDS traversal stack entries per lane (BuiltScene::stack_need)
+    uint32_t lds_surfaces;              // surfaces staged in LDS behind the stack by the quad kernels (rvb_lds_surfaces), 0 = none
     uint64_t ray_offset;
     float mic[3];
     float source[3];
@@ -44,6 +45,8 @@ struct TraceArgs {
 // Phase A: one lane per ray, the sequential closest-hit / reflect chain (kernel.cpp:359-375,
 // :459-461, :478, :492-501).  Leaves a work record per bounce in impulses[].
 void rvb_launch_path(const TraceArgs & a, hipStream_t s);
+// How many surfaces the quad kernels stage in LDS for this scene (all of them, or 0 when they would cost occupancy).
+uint32_t rvb_lds_surfaces(uint32_t stack_entries, uint64_t nsurfaces);
 // Phase C: one lane per (ray, bounce < 9): image-source validation (kernel.cpp:379-457) + slot 0.
 void rvb_launch_images(const TraceArgs & a, hipStream_t s);
 // Phase B: one lane per (ray, bounce): diffuse shadow ray to the microphone and the final

@@ -55,13 +55,24 @@ struct Stamps {
 
 struct Hit { float t; uint32_t tri; };
 
-// Streaming accesses to the 64-byte work records / Impulses (written once, read once): non-temporal,
-// so that the 819 MB stream does not evict the ~7 MB scene from the 4 MiB per-XCD L2s.
+// Streaming accesses to the 64-byte work records / Impulses (written once, read once by a later kernel).
+// RVB_STREAM_STORE picks the cache policy of the stores: 0 = nt (stays in the XCD's L2 until evicted),
+// 1 = sc1, 2 = sc0 sc1 (write-through, the line is DROPPED from L2 — MI355X_MICROARCH.md "stores of each
+// flavour"), so that the 819 MB record stream does not push the ~6 MB scene out of the 4 MiB per-XCD L2s.
+#ifndef RVB_STREAM_STORE
+#define RVB_STREAM_STORE 0
+#endif
 typedef float nt_float4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_stream(float4 * p, const float4 v)
 {
     nt_float4 t = {v.x, v.y, v.z, v.w};
+#if RVB_STREAM_STORE == 1
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(t) : "memory");
+#elif RVB_STREAM_STORE == 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(t) : "memory");
+#else
     __builtin_nontemporal_store(t, reinterpret_cast<nt_float4 *>(p));
+#endif
 }
 __device__ __forceinline__ float4 load_stream(const float4 * p)
 {
@@ -200,7 +211,10 @@ __device__ __forceinline__ void traverse_jobs(const SceneDev & sc, uint32_t * __
             uint32_t idx = NONE;
             if (c < count) {
                 const float4 * tp = reinterpret_cast<const float4 *>(sc.tris + first + c);
-                const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+                float4 ta = tp[0], tb = tp[1], tc = tp[2];
+                // all three loads leave before the first use: without this the compiler sinks the v0 load below the
+                // |det| test of mt_intersect and a leaf step pays two dependent round trips instead of one
+                asm volatile("" : "+v"(ta.x), "+v"(tb.x), "+v"(tc.x));
                 dist = mt_intersect(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), o, d);
                 idx = __float_as_uint(tc.y);
             }
@@ -268,6 +282,110 @@ __device__ __forceinline__ void traverse_jobs(const SceneDev & sc, uint32_t * __
         if ((threadIdx.x & 63u) == 0) atomicAdd(sc.stamps + 9, 1ull);
     }
 #endif
+#undef RVB_RESET_QUERY
+}
+
+// Closest-hit job loop with a per-iteration MAJORITY VOTE over the wave's 16 quads (path_kernel).
+// A quad is in one of three states: at a node, at a leaf, or done with its query.  The while-while loop above
+// runs node steps until the LAST quad has reached a leaf, so on incoherent rays (every bounce after the first)
+// only ~7 of 16 quads do useful work in a node step.  Here every iteration executes ONE step kind — the one most
+// quads are waiting for (ties: the cheaper kind) — for the quads in that state; the others keep their state.
+// Host replay of this policy on workload C2 (tools/travsim.cpp): wave-level node steps per bounce 37 -> 28,
+// quads active per node step 6.7 -> 8.9, wave instructions per bounce -14 %.  The votes are three ballots and
+// scalar popcounts per iteration.
+template <class Job>
+__device__ __forceinline__ void traverse_jobs_vote(const SceneDev & sc, uint32_t * __restrict__ stack, Job & job)
+{
+    const uint32_t c = threadIdx.x & 3u;
+    const uint32_t lane_base4 = (threadIdx.x & 60u) << 2;
+    const uint32_t lt_mask = (1u << c) - 1u;
+    const char * node_base = reinterpret_cast<const char *>(sc.nodes) + 16u * c;
+    const float neg_cull = -sc.cull_abs, cull_scale = 1.0f + sc.cull_rel;
+    v3 o = mk3(0, 0, 0), d = mk3(0, 0, 0);
+    float tmax = 0.0f;
+    float ix = 0.0f, iy = 0.0f, iz = 0.0f, oix = 0.0f, oiy = 0.0f, oiz = 0.0f, best_t = 0.0f;
+    uint32_t best_i = NONE, sp = 0, ref = 0;
+    bool active = job.next(o, d, tmax);
+#define RVB_RESET_QUERY()                                                         \
+    {                                                                             \
+        ix = clamp_inv(d.x); iy = clamp_inv(d.y); iz = clamp_inv(d.z);            \
+        oix = o.x * ix; oiy = o.y * iy; oiz = o.z * iz;                           \
+        best_t = __builtin_inff();                                                \
+        best_i = NONE; sp = 0; ref = 0;                                           \
+    }
+    if (active) RVB_RESET_QUERY()
+    for (;;) {
+        const bool at_node = active && !(ref & RVB_BVH_LEAF);
+        const bool at_leaf = active && (ref & RVB_BVH_LEAF) && ref != NONE;
+        const bool at_done = active && ref == NONE;
+        const int n_node = __popcll(__ballot(at_node)), n_leaf = __popcll(__ballot(at_leaf)), n_done = __popcll(__ballot(at_done));
+        if (n_node + n_leaf + n_done == 0)
+            break;
+        if (n_node >= n_leaf && n_node >= n_done) {
+            if (at_node) {
+                const uint4 n = *reinterpret_cast<const uint4 *>(node_base + ((size_t) ref << 6));
+                const float limit = fmaf(best_t, cull_scale, sc.cull_abs);
+                float tn;
+                const bool ok = slab(n, ix, iy, iz, oix, oiy, oiz, limit, neg_cull, tn);
+                const uint32_t cref = n.w;
+                const uint32_t key = ok ? ((__float_as_uint(fmaxf(tn, 0.0f)) & ~3u) | c) : NONE;
+                uint32_t kmin = min(key, dpp_u<QP_SWAP1>(key));
+                kmin = min(kmin, dpp_u<QP_SWAP2>(kmin));
+                if (kmin == NONE) {
+                    if (sp > 0) { --sp; ref = stack[sp * QUADS_PER_BLOCK]; } else ref = NONE;
+                } else {
+                    const uint32_t winner = kmin & 3u;
+                    const uint32_t rest = quad_ballot(ok) & ~(1u << winner);
+                    if (ok && c != winner)
+                        stack[(sp + __popc(rest & lt_mask)) * QUADS_PER_BLOCK] = cref;
+                    sp += __popc(rest);
+                    ref = (uint32_t) __builtin_amdgcn_ds_bpermute((int) (lane_base4 + (winner << 2)), (int) cref);
+                }
+            }
+        } else if (n_leaf >= n_done) {
+            if (at_leaf) {
+                const uint32_t first = ref & 0x0FFFFFFFu;
+                const uint32_t count = ((ref >> 28) & 7u) + 1u;
+                float dist = 0.0f;
+                uint32_t idx = NONE;
+                if (c < count) {
+                    const float4 * tp = reinterpret_cast<const float4 *>(sc.tris + first + c);
+                    float4 ta = tp[0], tb = tp[1], tc = tp[2];
+                    asm volatile("" : "+v"(ta.x), "+v"(tb.x), "+v"(tc.x));     // all three loads leave before the first use
+                    dist = mt_intersect(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), o, d);
+                    idx = __float_as_uint(tc.y);
+                }
+                // kernel.cpp:180-188 — smallest distance wins, equal distances go to the lower index
+                const bool valid = c < count && dist > RVB_EPSILON;
+                float rd = valid ? dist : __builtin_inff();
+                uint32_t ri = valid ? idx : NONE;
+                {
+                    const float od = dpp_f<QP_SWAP1>(rd);
+                    const uint32_t oi = dpp_u<QP_SWAP1>(ri);
+                    if (od < rd || (od == rd && oi < ri)) { rd = od; ri = oi; }
+                }
+                {
+                    const float od = dpp_f<QP_SWAP2>(rd);
+                    const uint32_t oi = dpp_u<QP_SWAP2>(ri);
+                    if (od < rd || (od == rd && oi < ri)) { rd = od; ri = oi; }
+                }
+                if (ri != NONE && (best_i == NONE || rd < best_t || (rd == best_t && ri < best_i))) {
+                    best_t = rd;
+                    best_i = ri;
+                }
+                if (sp > 0) { --sp; ref = stack[sp * QUADS_PER_BLOCK]; } else ref = NONE;
+            }
+        } else {
+            if (at_done) {
+                Hit h;
+                h.t = best_t;
+                h.tri = best_i;
+                job.done(best_i != NONE, h);
+                active = job.next(o, d, tmax);
+                if (active) RVB_RESET_QUERY()
+            }
+        }
+    }
 #undef RVB_RESET_QUERY
 }
 
@@ -377,6 +495,21 @@ __device__ __forceinline__ v3 ld3(const float * p) { return mk3(p[0], p[1], p[2]
 // shadow_kernel turns it into the final Impulse in place.
 // One ray's bounce chain as a Job: next() hands out the current ray, done() shades the hit
 // (kernel.cpp:459-461, :478), stores the work record and reflects (kernel.cpp:492-501).
+// Copies the scene's surface table (64 B per surface) behind the traversal stack in LDS when the launch reserved
+// room for it (TraceArgs::lds_surfaces = number of surfaces staged, 0 = none).  Single-wave workgroups: the
+// barrier is only the wait for the wave's own LDS writes.
+__device__ __forceinline__ const float4 * stage_surfaces(const TraceArgs & a, uint32_t * lds_after_stack)
+{
+    if (!a.lds_surfaces)
+        return nullptr;
+    float4 * dst = reinterpret_cast<float4 *>(lds_after_stack);
+    const float4 * src = reinterpret_cast<const float4 *>(a.scene.surfaces);
+    for (uint32_t i = threadIdx.x; i < 4u * a.lds_surfaces; i += WAVE)
+        dst[i] = src[i];
+    __syncthreads();
+    return dst;
+}
+
 struct PathJob {
     const TraceArgs & a;
     uint64_t ray;
@@ -387,6 +520,7 @@ struct PathJob {
     uint32_t index;
     bool alive;
     float4 * out;
+    const float4 * surf_lds;             // the surface table staged in LDS (stage_surfaces), or null: read it from HBM
 
     __device__ __forceinline__ bool next(v3 & o_, v3 & d_, float & tmax)
     {
@@ -406,8 +540,15 @@ struct PathJob {
         const float4 sh = reinterpret_cast<const float4 *>(a.scene.shade)[h.tri];
         const v3 normal = mk3(sh.x, sh.y, sh.z);
         const uint32_t surface = __float_as_uint(sh.w);
-        const float4 * sp = reinterpret_cast<const float4 *>(a.scene.surfaces + surface);
-        const float4 s0 = sp[0], s1 = sp[1];
+        // the specular row hangs off a dependent load (triangle -> surface -> row): from LDS it costs ~64 cycles
+        // instead of another L2 round trip in the middle of the ray's latency chain
+        float4 s0, s1;
+        if (surf_lds) {
+            s0 = surf_lds[4 * surface]; s1 = surf_lds[4 * surface + 1];
+        } else {
+            const float4 * sp = reinterpret_cast<const float4 *>(a.scene.surfaces + surface);
+            s0 = sp[0]; s1 = sp[1];
+        }
         const v3 p = o + d * h.t;                                    // kernel.cpp:459
         const float new_dist = distance + h.t;                       // kernel.cpp:460
         vol[0] = -vol[0] * s0.x; vol[1] = -vol[1] * s0.y; vol[2] = -vol[2] * s0.z; vol[3] = -vol[3] * s0.w;
@@ -435,13 +576,16 @@ __global__ __launch_bounds__(WAVE, 7) void path_kernel(TraceArgs a)
     extern __shared__ __attribute__((aligned(16))) uint32_t stack_lds[];   // [stack_entries][QUADS_PER_BLOCK]
     const uint32_t q = threadIdx.x >> 2;
     const uint64_t ray = (uint64_t) blockIdx.x * QUADS_PER_BLOCK + q;
+    const float4 * surf_lds = stage_surfaces(a, stack_lds + a.stack_entries * QUADS_PER_BLOCK);
     if (ray >= a.nrays)
         return;                                   // whole quads leave together
     const float4 d4 = a.directions[ray];
     PathJob job = {a, ray, threadIdx.x & 3u, ld3(a.source), mk3(d4.x, d4.y, d4.z), 0.0f,
                    {1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f}, 0u, true,
-                   reinterpret_cast<float4 *>(a.impulses + ray * a.nreflections)};
-#if RVB_PATH_JOBS
+                   reinterpret_cast<float4 *>(a.impulses + ray * a.nreflections), surf_lds};
+#if RVB_PATH_JOBS == 2
+    traverse_jobs_vote(a.scene, stack_lds + q, job);
+#elif RVB_PATH_JOBS
     traverse_jobs<false>(a.scene, stack_lds + q, job);
 #else
     v3 o, d;
@@ -606,6 +750,7 @@ struct ShadowJob {
     float diff, new_dist, mag;
     uint32_t surface;
     float tmin, tmax_seen;               // arrival-time range of the non-zero impulses this lane's quad produced
+    const float4 * surf_lds;             // surface table in LDS, or null
 
     __device__ __forceinline__ bool next(v3 & o_, v3 & d_, float & tmax)
     {
@@ -646,7 +791,8 @@ struct ShadowJob {
         const float e2 = dpp_f<0xED>(eA), e3 = dpp_f<0xED>(eB);     // quad_perm [1,3,2,3]: lane 0 <- 1, lane 1 <- 3
         if (c < 2) {
             if (visible) {
-                const float4 dc = reinterpret_cast<const float4 *>(a.scene.surfaces + surface)[2 + c];   // diffuse
+                const float4 dc = surf_lds ? surf_lds[4 * surface + 2 + c]
+                                           : reinterpret_cast<const float4 *>(a.scene.surfaces + surface)[2 + c];   // diffuse
                 // kernel.cpp:480-485: newVol * attenuation * diffuse * DIFF, left to right
                 o.x = ((mine.x * e0) * dc.x) * diff;
                 o.y = ((mine.y * e1) * dc.y) * diff;
@@ -685,6 +831,7 @@ __global__ __launch_bounds__(WAVE, 7) void shadow_kernel(TraceArgs a)
     job.airB = a.air[2 * c + 1];
     job.tmin = __builtin_inff();
     job.tmax_seen = 0.0f;
+    job.surf_lds = stage_surfaces(a, stack_lds + a.stack_entries * QUADS_PER_BLOCK);
 #if RVB_SHADOW_JOBS
     traverse_jobs<true>(a.scene, stack_lds + q, job);
 #else
@@ -710,11 +857,28 @@ __global__ __launch_bounds__(WAVE, 7) void shadow_kernel(TraceArgs a)
 
 }  // namespace
 
+// LDS of a quad kernel's single-wave workgroup: the traversal stack, then (optionally) the surface table
+static size_t quad_kernel_lds_bytes(const TraceArgs & a)
+{
+    return a.stack_entries * QUADS_PER_BLOCK * sizeof(uint32_t) + (size_t) a.lds_surfaces * sizeof(rvb_surface);
+}
+
+uint32_t rvb_lds_surfaces(uint32_t stack_entries, uint64_t nsurfaces)
+{
+    // 7 waves/SIMD = 28 single-wave workgroups per CU must still fit in the CU's 160 KiB of LDS
+    static const bool off = getenv("RVB_LDS_SURFACES") && getenv("RVB_LDS_SURFACES")[0] == '0';
+    const size_t budget = (160u * 1024u) / 28u;
+    const size_t stack = (size_t) stack_entries * QUADS_PER_BLOCK * sizeof(uint32_t);
+    if (off || nsurfaces == 0 || stack + nsurfaces * sizeof(rvb_surface) > budget)
+        return 0;
+    return (uint32_t) nsurfaces;
+}
+
 void rvb_launch_path(const TraceArgs & a, hipStream_t s)
 {
     if (a.nrays == 0) return;
     const unsigned blocks = (unsigned) ((a.nrays + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK);
-    hipLaunchKernelGGL(path_kernel, dim3(blocks), dim3(WAVE), a.stack_entries * QUADS_PER_BLOCK * sizeof(uint32_t), s, a);
+    hipLaunchKernelGGL(path_kernel, dim3(blocks), dim3(WAVE), quad_kernel_lds_bytes(a), s, a);
 }
 
 void rvb_launch_images(const TraceArgs & a, hipStream_t s)
@@ -731,5 +895,5 @@ void rvb_launch_shadow(const TraceArgs & a, hipStream_t s)
     uint64_t blocks = (total + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK;
     static const uint64_t per_cu = getenv("RVB_SHADOW_WG_PER_CU") ? strtoull(getenv("RVB_SHADOW_WG_PER_CU"), nullptr, 10) : 256;
     if (blocks > 256u * per_cu) blocks = 256u * per_cu;     // single-wave workgroups per CU; records beyond are grid-strided
-    hipLaunchKernelGGL(shadow_kernel, dim3((unsigned) blocks), dim3(WAVE), a.stack_entries * QUADS_PER_BLOCK * sizeof(uint32_t), s, a);
+    hipLaunchKernelGGL(shadow_kernel, dim3((unsigned) blocks), dim3(WAVE), quad_kernel_lds_bytes(a), s, a);
 }

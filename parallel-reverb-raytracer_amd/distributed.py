@@ -3,11 +3,12 @@ RCCL over xGMI on ROCm; "gloo" in the CPU tests).
 
 The path shards by rays: the scene is replicated, rank r traces the contiguous ray
 range [r*n, (r+1)*n) of one seeded global ray set, and the only data-path collective is ONE
-all-reduce(sum) of the [channels][8][nbins] histograms.  Two tiny control exchanges make the shards
-agree on the binning: an all-reduce(max) of (-min_nonzero_time, max_time) — the inputs of findPredelay
-(reference rayverb.h:49-74) and MAX_SAMPLE (rayverb.cpp:57) — and an all-gather of the few valid
-image-source candidates, merged with the reference's "lowest ray index wins" rule (rayverb.cpp:654-676)
-on rank 0, which alone adds the merged image impulses to its histogram.
+all-reduce(sum) of the [channels][8][nbins] histograms.  ONE small control collective makes the shards
+agree on the binning: an all-gather of a few-KB block per rank holding the shard's diffuse time range
+— the inputs of findPredelay (reference rayverb.h:49-74) and MAX_SAMPLE (rayverb.cpp:57) — and its
+few valid image-source candidates.  Every rank merges the candidates itself with the reference's
+"lowest ray index wins" rule (rayverb.cpp:654-676), so all ranks know the global time range without a
+second exchange; rank 0 alone adds the merged image impulses to its histogram.
 
 `tracer` is a capi.Context (GPU) or any object with the same methods (the CPU tests drive this module
 with an oracle-backed stand-in).
@@ -25,57 +26,113 @@ def shard_range(total_rays, rank, world):
     return first, base + (1 if rank < extra else 0)
 
 
-def reduce_time_range(lo, hi, group_world, device):
-    """Global (min non-zero, max) of the per-rank attenuated-time ranges; lo == 0 means "none"."""
-    if group_world == 1:
-        return lo, hi
+EXCHANGE_CAPACITY = 64          # image-source candidates per rank carried by the first (normally only) exchange
+_HEADER_BYTES = 16              # u64 candidate count, f32 min non-zero time, f32 max time
+
+
+def _pack_block(candidates, lo, hi, capacity):
+    block = np.zeros(_HEADER_BYTES + capacity * capi.IMAGE_CANDIDATE.itemsize, dtype=np.uint8)
+    block[:8] = np.frombuffer(np.uint64(candidates.shape[0]).tobytes(), dtype=np.uint8)
+    block[8:16] = np.frombuffer(np.array([lo, hi], dtype=np.float32).tobytes(), dtype=np.uint8)
+    n = min(int(candidates.shape[0]), capacity)
+    if n:
+        block[_HEADER_BYTES:_HEADER_BYTES + n * capi.IMAGE_CANDIDATE.itemsize] = \
+            np.frombuffer(np.ascontiguousarray(candidates[:n]).tobytes(), dtype=np.uint8)
+    return block
+
+
+def _unpack_block(block, capacity):
+    count = int(np.frombuffer(block[:8].tobytes(), dtype=np.uint64)[0])
+    lo, hi = (float(x) for x in np.frombuffer(block[8:16].tobytes(), dtype=np.float32))
+    n = min(count, capacity)
+    cand = np.frombuffer(block[_HEADER_BYTES:_HEADER_BYTES + n * capi.IMAGE_CANDIDATE.itemsize].tobytes(),
+                         dtype=capi.IMAGE_CANDIDATE).copy()
+    return count, lo, hi, cand
+
+
+def exchange_shard_summaries(candidates, lo, hi, world, device, capacity=None):
+    """The ONE control collective of a multi-GPU impulse response: an all-gather of a small fixed-size
+    block per rank = (number of valid image-source candidates, min non-zero / max diffuse time of the
+    shard, the candidates themselves).  Returns (all candidates in rank order, [(lo, hi)] per rank).
+    A shard with more than `capacity` candidates (rare: a few per 100k rays are typical) triggers one
+    more all-gather sized for the largest shard; every rank sees the same counts, so all ranks agree
+    on whether that second round happens."""
     import torch
     import torch.distributed as dist
-    sentinel = -3.0e38
-    r = torch.tensor([-lo if lo > 0 else sentinel, hi], device=device, dtype=torch.float32)
-    dist.all_reduce(r, op=dist.ReduceOp.MAX)
-    r = r.cpu()
-    return (float(-r[0]) if float(r[0]) > sentinel else 0.0), float(r[1])
+    capacity = EXCHANGE_CAPACITY if capacity is None else capacity
+    while True:
+        mine = torch.from_numpy(_pack_block(candidates, lo, hi, capacity)).to(device)
+        blocks = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(blocks, mine)
+        parts = [_unpack_block(b.cpu().numpy(), capacity) for b in blocks]
+        worst = max(p[0] for p in parts)
+        if worst <= capacity:
+            return np.concatenate([p[3] for p in parts]), [(p[1], p[2]) for p in parts]
+        capacity = worst
 
 
-def gather_candidates(candidates, group_world):
-    if group_world == 1:
-        return candidates
-    import torch.distributed as dist
-    gathered = [None] * group_world
-    dist.all_gather_object(gathered, candidates)
-    return np.concatenate(gathered)
+def combine_time_ranges(ranges):
+    """(min non-zero, max) over (lo, hi) pairs in which lo == 0 means "no non-zero time"."""
+    los = [lo for lo, _ in ranges if lo > 0]
+    return (min(los) if los else 0.0), max([hi for _, hi in ranges] + [0.0])
 
 
 def generate_ir(tracer, mic, source, nreflections, air, speakers_dir, speakers_coeff, sample_rate,
                 trim_predelay=True, mode=capi.IR_FAST, rank=0, world=1, ray_offset=0, device="cpu",
                 which=capi.IR_ALL, remove_direct=False, on_stage=None):
     """One impulse response from the rays already set on `tracer`.  Returns (hist tensor
-    [nchannels][8][nbins] — identical on every rank —, info dict)."""
+    [nchannels][8][nbins] — identical on every rank —, info dict).
+
+    world == 1: trace -> merge image sources -> time range -> bin.
+    world > 1: two collectives in all.  (1) exchange_shard_summaries: every rank learns every shard's
+    image-source candidates and diffuse time range, merges the candidates itself (deterministic, a few
+    dozen records) and so knows the global predelay / length without a further exchange; (2) the
+    all-reduce(sum) of the histograms.  Only rank 0 adds the merged image impulses to its histogram."""
     import torch
     import torch.distributed as dist
 
+    empty = np.zeros(0, dtype=IMPULSE)
     tracer.trace(mic, source, nreflections, air, ray_offset=ray_offset)
     candidates = tracer.get_image_candidates()           # small: valid image-source paths only
     if on_stage:
         on_stage("trace")
     direct = tracer.get_direct()
-    candidates = gather_candidates(candidates, world)
-    if rank == 0 and (which & capi.IR_IMAGES):
-        images = capi.merge_images(candidates, direct, remove_direct)
+    want_images = bool(which & capi.IR_IMAGES)
+    if world == 1:
+        images = capi.merge_images(candidates, direct, remove_direct) if want_images else empty
+        tracer.ir_configure_speakers(mic, speakers_dir, speakers_coeff, which, images)
+        lo, hi = tracer.ir_time_range()
+        if on_stage:
+            on_stage("time_range")
+        contributes = True
     else:
-        images = np.zeros(0, dtype=IMPULSE)
-    tracer.ir_configure_speakers(mic, speakers_dir, speakers_coeff, which, images)
-    lo, hi = tracer.ir_time_range()
-    if on_stage:
-        on_stage("time_range")
-    lo, hi = reduce_time_range(lo, hi, world, device)
+        ranges = []
+        lo_d = hi_d = 0.0
+        if which & capi.IR_DIFFUSE:                      # this shard's diffuse impulses alone
+            tracer.ir_configure_speakers(mic, speakers_dir, speakers_coeff, capi.IR_DIFFUSE, empty)
+            lo_d, hi_d = tracer.ir_time_range()
+            if on_stage:
+                on_stage("time_range")
+        candidates, shard_ranges = exchange_shard_summaries(candidates, lo_d, hi_d, world, device)
+        ranges += shard_ranges
+        images = capi.merge_images(candidates, direct, remove_direct) if want_images else empty
+        if images.shape[0]:                              # the merged images' own range, the same on every rank
+            tracer.ir_configure_speakers(mic, speakers_dir, speakers_coeff, capi.IR_IMAGES, images)
+            ranges.append(tracer.ir_time_range())
+        lo, hi = combine_time_ranges(ranges)
+        mine = which if rank == 0 else (which & capi.IR_DIFFUSE)
+        contributes = mine != 0
+        if contributes:
+            tracer.ir_configure_speakers(mic, speakers_dir, speakers_coeff, mine, images if rank == 0 else empty)
+        if rank != 0:
+            images = empty
     predelay = lo if trim_predelay else 0.0
     nbins = tracer.ir_bins(hi, predelay, sample_rate)
     hist = torch.zeros((len(speakers_coeff), 8, nbins), device=device, dtype=torch.float32)
     if hist.is_cuda:
         torch.cuda.synchronize()                         # the zero fill ran on torch's stream
-    tracer.ir_accumulate_tensor(predelay, sample_rate, nbins, mode, hist)
+    if contributes:
+        tracer.ir_accumulate_tensor(predelay, sample_rate, nbins, mode, hist)
     if on_stage:
         on_stage("accumulate")
     tracer.synchronize()

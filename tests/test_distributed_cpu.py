@@ -19,7 +19,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, out_dir, total_rays, nrefl):
+def _worker(rank, world, port, out_dir, total_rays, nrefl, capacity=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -32,6 +32,8 @@ def _worker(rank, world, port, out_dir, total_rays, nrefl):
     from parallel_reverb_raytracer_amd import capi, distributed, dtypes, scenes
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
+    if capacity is not None:
+        distributed.EXCHANGE_CAPACITY = capacity     # force the second (overflow) round of the control all-gather
     scene, info = scenes.cathedral(1200)
     first, count = distributed.shard_range(total_rays, rank, world)
     dirs = scenes.sphere_directions(count, seed=9, first=first)
@@ -39,7 +41,7 @@ def _worker(rank, world, port, out_dir, total_rays, nrefl):
     hist, meta = distributed.generate_ir(tracer, info["mic"], info["source"], nrefl, dtypes.AIR_COEFFICIENTS,
                                          [(-1, 0, -1), (1, 0, -1)], [0.5, 0.5], 44100.0, trim_predelay=True,
                                          mode=capi.IR_EXACT, rank=rank, world=world, ray_offset=first, device="cpu")
-    np.savez(os.path.join(out_dir, "rank%d_of%d.npz" % (rank, world)), hist=hist.numpy(), nbins=meta["nbins"],
+    np.savez(os.path.join(out_dir, "rank%d_of%d%s.npz" % (rank, world, "" if capacity is None else "_cap%d" % capacity)), hist=hist.numpy(), nbins=meta["nbins"],
              predelay=meta["predelay"], images=meta["images"])
     if world > 1:
         dist.barrier()
@@ -72,3 +74,23 @@ def test_two_rank_gloo_equals_single_process(tmp_path, oracle):
     scale = np.abs(a).max(axis=2, keepdims=True) + 1e-30
     assert (np.abs(a - b) <= 1e-5 * scale).all()
     assert np.abs(a).sum() > 0
+
+
+def test_candidate_exchange_overflow_round(tmp_path, oracle):
+    """A shard with more image-source candidates than the first all-gather carries triggers exactly one more
+    round; the result is the one of the roomy exchange."""
+    import torch.multiprocessing as mp
+    total_rays, nrefl = 96, 10
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), total_rays, nrefl), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), total_rays, nrefl, 0), nprocs=2, join=True)
+    roomy = np.load(os.path.join(str(tmp_path), "rank0_of2.npz"))
+    tight = np.load(os.path.join(str(tmp_path), "rank0_of2_cap0.npz"))
+    assert int(roomy["images"]) >= 2, "the case needs at least one candidate besides the direct path"
+    assert np.array_equal(roomy["hist"], tight["hist"]) and int(roomy["images"]) == int(tight["images"])
+
+
+def test_time_range_combination():
+    from parallel_reverb_raytracer_amd import distributed
+    assert distributed.combine_time_ranges([(0.0, 0.0), (0.5, 2.0), (0.25, 1.0)]) == (0.25, 2.0)
+    assert distributed.combine_time_ranges([(0.0, 0.0)]) == (0.0, 0.0)
+    assert distributed.combine_time_ranges([]) == (0.0, 0.0)

@@ -1,0 +1,310 @@
+// travsim.cpp — developer tool (CPU only, not part of the product or the tests): replays the quad
+// traversal of csrc/trace_kernels.hip on the host for a dumped scene and counts ray-level and
+// wave-level steps under alternative traversal policies, so that a policy can be judged before a
+// GPU run is spent on it.  Uses the product's own BVH builder and triangle arithmetic.
+//
+//   travsim <tris.bin> <verts.bin> <dirs.bin> <nrays> <nrefl> sx sy sz mx my mz
+#include "../parallel-reverb-raytracer_amd/csrc/bvh.h"
+#include "../parallel-reverb-raytracer_amd/csrc/rvb_math.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+static std::vector<char> slurp(const char * path)
+{
+    FILE * f = fopen(path, "rb");
+    if (!f) { perror(path); exit(1); }
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::vector<char> b(n);
+    if (fread(b.data(), 1, n, f) != (size_t) n) exit(1);
+    fclose(f);
+    return b;
+}
+
+static float half_to_float(uint16_t b)
+{
+    _Float16 h;
+    memcpy(&h, &b, 2);
+    return (float) h;
+}
+
+struct Policy {
+    bool stack_dist = false;     // stack entries carry the entry distance; culled at pop time without a node visit
+    bool sorted_push = false;    // siblings pushed far-to-near (nearest popped first) instead of lane order
+    int postpone = 0;            // leaves a quad may hold back while it keeps walking nodes (Aila-Laine speculative traversal)
+};
+
+struct Query {
+    v3 o, d;
+    float ix, iy, iz, oix, oiy, oiz;
+    float best_t, tmax;
+    uint32_t best_i;
+    bool any;
+    uint32_t ref;
+    std::vector<uint32_t> stack;
+    std::vector<float> stack_t;
+    bool found = false;
+    std::vector<uint32_t> held;  // postponed leaves
+};
+
+static float clamp_inv(float d)
+{
+    float inv = 1.0f / d;
+    if (inv > 1e30f) inv = 1e30f;
+    if (inv < -1e30f) inv = -1e30f;
+    return inv;
+}
+
+struct Sim {
+    BuiltScene bs;
+    float cull_abs, cull_rel;
+    Policy pol;
+    // counters
+    unsigned long long node_steps = 0, node_steps_allculled = 0, leaf_steps = 0, pop_culls = 0, pushes = 0;
+
+    void begin(Query & q, v3 o, v3 d, bool any, float tmax)
+    {
+        q.o = o; q.d = d; q.any = any; q.tmax = tmax;
+        q.ix = clamp_inv(d.x); q.iy = clamp_inv(d.y); q.iz = clamp_inv(d.z);
+        q.oix = o.x * q.ix; q.oiy = o.y * q.iy; q.oiz = o.z * q.iz;
+        q.best_t = any ? tmax : __builtin_inff();
+        q.best_i = 0xFFFFFFFFu;
+        q.ref = 0;
+        q.stack.clear(); q.stack_t.clear();
+        q.found = false;
+        q.held.clear();
+    }
+    float limit(const Query & q) const { return fmaf(q.best_t, 1.0f + cull_rel, cull_abs); }
+    void pop(Query & q)
+    {
+        for (;;) {
+            if (q.stack.empty()) { q.ref = 0xFFFFFFFFu; return; }
+            q.ref = q.stack.back();
+            float t = q.stack_t.back();
+            q.stack.pop_back(); q.stack_t.pop_back();
+            if (pol.stack_dist && t > limit(q)) { ++pop_culls; continue; }
+            return;
+        }
+    }
+    // one node step; q.ref must be a node
+    void node_step(Query & q)
+    {
+        ++node_steps;
+        const BvhNode & n = bs.nodes[q.ref];
+        const float lim = limit(q), neg_cull = -cull_abs;
+        bool ok[4]; float tn[4];
+        int nok = 0;
+        for (int c = 0; c < 4; ++c) {
+            const BvhChild & ch = n.c[c];
+            float lox = half_to_float(ch.lox), loy = half_to_float(ch.loy), loz = half_to_float(ch.loz);
+            float hix = half_to_float(ch.hix), hiy = half_to_float(ch.hiy), hiz = half_to_float(ch.hiz);
+            float tx0 = fmaf(lox, q.ix, -q.oix), tx1 = fmaf(hix, q.ix, -q.oix);
+            float ty0 = fmaf(loy, q.iy, -q.oiy), ty1 = fmaf(hiy, q.iy, -q.oiy);
+            float tz0 = fmaf(loz, q.iz, -q.oiz), tz1 = fmaf(hiz, q.iz, -q.oiz);
+            float a = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), neg_cull));
+            float b = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), lim));
+            ok[c] = a <= b && ch.ref != RVB_BVH_EMPTY;
+            tn[c] = fmaxf(a, 0.0f);
+            nok += ok[c];
+        }
+        if (!nok) { ++node_steps_allculled; pop(q); return; }
+        int winner = -1;
+        if (q.any) { for (int c = 0; c < 4; ++c) if (ok[c]) { winner = c; break; } }
+        else {
+            uint32_t bestk = 0xFFFFFFFFu;
+            for (int c = 0; c < 4; ++c) if (ok[c]) {
+                uint32_t fb; memcpy(&fb, &tn[c], 4);
+                uint32_t k = (fb & ~3u) | c;
+                if (k < bestk) { bestk = k; winner = c; }
+            }
+        }
+        int order[4], m = 0;
+        for (int c = 0; c < 4; ++c) if (ok[c] && c != winner) order[m++] = c;
+        if (pol.sorted_push && !q.any) {                       // far first
+            for (int i = 0; i < m; ++i) for (int j = i + 1; j < m; ++j) if (tn[order[j]] > tn[order[i]]) { int t = order[i]; order[i] = order[j]; order[j] = t; }
+        }
+        for (int i = 0; i < m; ++i) { q.stack.push_back(n.c[order[i]].ref); q.stack_t.push_back(tn[order[i]]); ++pushes; }
+        q.ref = n.c[winner].ref;
+    }
+    // one leaf step; returns true when the query has finished
+    bool leaf_step(Query & q)
+    {
+        ++leaf_steps;
+        const uint32_t first = q.ref & 0x0FFFFFFFu, count = ((q.ref >> 28) & 7u) + 1u;
+        for (uint32_t j = 0; j < count; ++j) {
+            const BvhTri & t = bs.tris[first + j];
+            float dist = mt_intersect(mk3(t.v0[0], t.v0[1], t.v0[2]), mk3(t.e0[0], t.e0[1], t.e0[2]), mk3(t.e1[0], t.e1[1], t.e1[2]), q.o, q.d);
+            if (q.any) { if (dist > RVB_EPSILON && dist <= q.tmax) q.found = true; }
+            else if (dist > RVB_EPSILON && (q.best_i == 0xFFFFFFFFu || dist < q.best_t || (dist == q.best_t && t.index < q.best_i))) { q.best_t = dist; q.best_i = t.index; }
+        }
+        if (q.found) return true;
+        pop(q);
+        return q.ref == 0xFFFFFFFFu;
+    }
+};
+
+struct Ray { v3 o, d; uint32_t bounce; bool alive; };
+
+int main(int argc, char ** argv)
+{
+    if (argc < 12) { fprintf(stderr, "usage\n"); return 1; }
+    auto tb = slurp(argv[1]), vb = slurp(argv[2]), db = slurp(argv[3]);
+    const uint64_t ntri = tb.size() / 32, nvert = vb.size() / 16;
+    uint64_t nrays = strtoull(argv[4], 0, 10);
+    const uint32_t nrefl = atoi(argv[5]);
+    if (nrays > db.size() / 16) nrays = db.size() / 16;
+    v3 src = mk3(atof(argv[6]), atof(argv[7]), atof(argv[8])), mic = mk3(atof(argv[9]), atof(argv[10]), atof(argv[11]));
+    Sim base;
+    std::string err = rvb_build_scene((const rvb_triangle *) tb.data(), ntri, (const rvb_float3 *) vb.data(), nvert, 1000, base.bs);
+    if (!err.empty()) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+    base.cull_abs = base.bs.pad; base.cull_rel = 1e-4f;
+    printf("nodes %zu tris %zu depth %u stack_need %u\n", base.bs.nodes.size(), base.bs.tris.size(), base.bs.depth, base.bs.stack_need);
+    const float * dirs = (const float *) db.data();
+
+    const double C_NODE = 48, C_LEAF = 120, C_DONE = 110;        // wave instructions per step (from the ISA)
+    for (int p = 0; p < 6; ++p) {
+        Sim s = base;
+        s.pol.stack_dist = 0; s.pol.sorted_push = 0; s.pol.postpone = 0;
+        // scheduler: 0 = while-while (shipped); 1 = majority vote; 2..: node loop runs while >= T quads want a node step
+        const int sched = p;
+        const int T = p >= 2 ? (p - 1) * 2 : 1;
+        unsigned long long w_node = 0, w_leaf = 0, w_done = 0, bounces = 0, q_node_active = 0, q_leaf_active = 0, q_done_active = 0, maxstack = 0;
+        std::vector<v3> hitpts; std::vector<uint32_t> hittri;
+        for (uint64_t w = 0; w < nrays; w += 16) {
+            Query q[16]; Ray r[16];
+            enum { NODE, LEAF, DONE, IDLE } st[16];
+            int nq = (int) std::min<uint64_t>(16, nrays - w);
+            for (int i = 0; i < 16; ++i) st[i] = IDLE;
+            for (int i = 0; i < nq; ++i) {
+                r[i].o = src; r[i].d = mk3(dirs[4 * (w + i)], dirs[4 * (w + i) + 1], dirs[4 * (w + i) + 2]); r[i].bounce = 0; r[i].alive = true;
+                s.begin(q[i], r[i].o, r[i].d, false, 0.0f);
+                st[i] = NODE;
+            }
+            auto classify = [&](int i) {
+                if (q[i].ref == 0xFFFFFFFFu) st[i] = DONE;
+                else st[i] = (q[i].ref & RVB_BVH_LEAF) ? LEAF : NODE;
+            };
+            int phase = 0;   // while-while emulation
+            for (;;) {
+                int cn = 0, cl = 0, cd = 0;
+                for (int i = 0; i < nq; ++i) { cn += st[i] == NODE; cl += st[i] == LEAF; cd += st[i] == DONE; }
+                if (cn + cl + cd == 0) break;
+                int act;
+                if (sched == 0) {
+                    // node while any; then one leaf; then done; repeat
+                    if (phase == 0) { if (cn) act = NODE; else { phase = 1; continue; } }
+                    else if (phase == 1) { phase = 2; if (cl) act = LEAF; else continue; }
+                    else { phase = 0; if (cd) act = DONE; else continue; }
+                } else if (sched == 1) {
+                    act = NODE; int best = cn;
+                    if (cl > best) { act = LEAF; best = cl; }
+                    if (cd > best) { act = DONE; best = cd; }
+                } else if (sched >= 2 && sched <= 5) {
+                    const double alpha = -0.25 * (sched - 1);
+                    double sn = cn / pow(C_NODE, alpha), sl = cl / pow(C_LEAF, alpha), sd = cd / pow(C_DONE, alpha);
+                    act = NODE; double best = sn;
+                    if (sl > best) { act = LEAF; best = sl; }
+                    if (sd > best) { act = DONE; best = sd; }
+                } else {
+                    if (cn >= T || (cl == 0 && cd == 0)) act = NODE;
+                    else if (cl >= cd && cl) act = LEAF;
+                    else if (cd) act = DONE;
+                    else act = LEAF;
+                }
+                if (act == NODE) {
+                    ++w_node; q_node_active += cn;
+                    for (int i = 0; i < nq; ++i) if (st[i] == NODE) { s.node_step(q[i]); classify(i); if (q[i].stack.size() > maxstack) maxstack = q[i].stack.size(); }
+                } else if (act == LEAF) {
+                    ++w_leaf; q_leaf_active += cl;
+                    for (int i = 0; i < nq; ++i) if (st[i] == LEAF) { bool f = s.leaf_step(q[i]); if (f) st[i] = DONE; else classify(i); }
+                } else {
+                    ++w_done; q_done_active += cd;
+                    for (int i = 0; i < nq; ++i) if (st[i] == DONE) {
+                        if (q[i].best_i == 0xFFFFFFFFu) { st[i] = IDLE; continue; }
+                        ++bounces;
+                        const TriShade & sh = s.bs.shade[q[i].best_i];
+                        v3 n = mk3(sh.n[0], sh.n[1], sh.n[2]);
+                        v3 pnt = r[i].o + r[i].d * q[i].best_t;
+                        if (hitpts.size() < 400000) { hitpts.push_back(pnt); hittri.push_back(q[i].best_i); }
+                        r[i].d = reflect3(n, r[i].d);
+                        r[i].o = pnt;
+                        if (++r[i].bounce >= nrefl) { st[i] = IDLE; continue; }
+                        s.begin(q[i], r[i].o, r[i].d, false, 0.0f);
+                        st[i] = NODE;
+                    }
+                }
+            }
+        }
+        const double wn = 16.0 * w_node / bounces, wl = 16.0 * w_leaf / bounces, wd = 16.0 * w_done / bounces;
+        printf("sched %d T %d | ray node %.2f leaf %.2f | wave node %.2f leaf %.2f done %.2f | active node %.1f leaf %.1f done %.1f | cost/bounce %.0f\n",
+               sched, T, (double) s.node_steps / bounces, (double) s.leaf_steps / bounces, wn, wl, wd,
+               (double) q_node_active / w_node, (double) q_leaf_active / w_leaf, (double) q_done_active / w_done,
+               wn * C_NODE + wl * C_LEAF + wd * C_DONE);
+        if (p > 1) continue;
+        // ---- shadow_kernel replay: records grouped by leaf position, 16 consecutive records per wave pass
+        {
+            std::vector<uint32_t> order(hitpts.size());
+            for (size_t i = 0; i < order.size(); ++i) order[i] = (uint32_t) i;
+            std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return base.bs.leafpos[hittri[a]] < base.bs.leafpos[hittri[b]]; });
+            const double CS_NODE = 40, CS_LEAF = 100, CS_DONE = 150;
+            for (int mode = 0; mode < 3; ++mode) {       // 0 lockstep passes (shipped), 1 job loop while-while, 2 job loop majority vote
+                Sim sh = base;
+                unsigned long long w_node = 0, w_leaf = 0, w_done = 0, an = 0, al = 0, ad = 0;
+                const size_t J = 32;                      // records per quad in the job-loop modes
+                const size_t per_wave = mode == 0 ? 16 : 16 * J;
+                for (size_t w0 = 0; w0 + per_wave <= order.size(); w0 += per_wave) {
+                    Query q[16];
+                    enum { NODE, LEAF, DONE, IDLE } st[16];
+                    size_t nextj[16];
+                    auto start = [&](int i) {
+                        if (nextj[i] >= (mode == 0 ? 1 : J)) { st[i] = IDLE; return; }
+                        const v3 pnt = hitpts[order[w0 + nextj[i] * 16 + i]];
+                        ++nextj[i];
+                        v3 b2p = mic - pnt;
+                        sh.begin(q[i], pnt, normalize3(b2p), true, length3(b2p));
+                        st[i] = NODE;
+                    };
+                    for (int i = 0; i < 16; ++i) { nextj[i] = 0; start(i); }
+                    auto classify = [&](int i) {
+                        if (q[i].ref == 0xFFFFFFFFu) st[i] = DONE;
+                        else st[i] = (q[i].ref & RVB_BVH_LEAF) ? LEAF : NODE;
+                    };
+                    int phase = 0;
+                    for (;;) {
+                        int cn = 0, cl = 0, cd = 0;
+                        for (int i = 0; i < 16; ++i) { cn += st[i] == NODE; cl += st[i] == LEAF; cd += st[i] == DONE; }
+                        if (cn + cl + cd == 0) break;
+                        int act;
+                        if (mode == 0) {
+                            // traverse_quad per record: node while any, leaf, repeat until all finished; then one done for all
+                            if (cn) act = NODE; else if (cl) act = LEAF; else act = DONE;
+                        } else if (mode == 1) {
+                            if (phase == 0) { if (cn) act = NODE; else { phase = 1; continue; } }
+                            else if (phase == 1) { phase = 2; if (cl) act = LEAF; else continue; }
+                            else { phase = 0; if (cd) act = DONE; else continue; }
+                        } else {
+                            act = NODE; int best = cn;
+                            if (cl > best) { act = LEAF; best = cl; }
+                            if (cd > best) { act = DONE; best = cd; }
+                        }
+                        if (act == NODE) { ++w_node; an += cn; for (int i = 0; i < 16; ++i) if (st[i] == NODE) { sh.node_step(q[i]); classify(i); } }
+                        else if (act == LEAF) { ++w_leaf; al += cl; for (int i = 0; i < 16; ++i) if (st[i] == LEAF) { bool f = sh.leaf_step(q[i]); if (f) st[i] = DONE; else classify(i); } }
+                        else { ++w_done; ad += cd; for (int i = 0; i < 16; ++i) if (st[i] == DONE) start(i); }
+                    }
+                }
+                const double nrec = (double) (order.size() / per_wave * per_wave);
+                const double wn = 16.0 * w_node / nrec, wl = 16.0 * w_leaf / nrec, wd = 16.0 * w_done / nrec;
+                printf("   shadow mode %d | ray node %.2f leaf %.2f | wave node %.2f leaf %.2f done %.2f | active node %.1f leaf %.1f done %.1f | cost/record %.0f\n",
+                       mode, sh.node_steps / nrec, sh.leaf_steps / nrec, wn, wl, wd, (double) an / w_node, (double) al / w_leaf, (double) ad / w_done,
+                       wn * CS_NODE + wl * CS_LEAF + wd * CS_DONE);
+            }
+        }
+    }
+    return 0;
+}
