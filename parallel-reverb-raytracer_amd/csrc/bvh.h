@@ -27,12 +27,13 @@
 
 #define RVB_BVH_EMPTY 0xFFFFFFFFu
 #define RVB_BVH_LEAF 0x80000000u
+#define RVB_BVH_NODE_SHIFT 6         // node references are BYTE offsets (index * 64): one 32-bit add forms the load address
 #define RVB_BVH_MAX_LEAF 4
 #define RVB_BVH_STACK 64            // per-lane traversal stack entries (LDS)
 
 struct BvhChild {                   // 16 B = one 16-byte load
     uint16_t lox, loy, loz, hix, hiy, hiz;   // binary16 bit patterns
-    uint32_t ref;                   // EMPTY | LEAF|(count-1)<<28|first | node index
+    uint32_t ref;                   // EMPTY | LEAF|(count-1)<<28|first | node index << RVB_BVH_NODE_SHIFT
 };
 struct BvhNode { BvhChild c[4]; };  // 64 B
 

@@ -204,8 +204,8 @@ std::string rvb_build_scene(const rvb_triangle * triangles, uint64_t ntriangles,
                             const rvb_float3 * vertices, uint64_t nvertices,
                             uint64_t nsurfaces, BuiltScene & out)
 {
-    if (ntriangles >= (1ull << 28))
-        return "too many triangles (limit 2^28)";
+    if (ntriangles >= (1ull << 25))
+        return "too many triangles (limit 2^25: node references are 31-bit byte offsets of 64-byte nodes)";
     out = BuiltScene();
     out.shade.resize(ntriangles);
     out.corners.resize(ntriangles);
@@ -363,7 +363,7 @@ std::string rvb_build_scene(const rvb_triangle * triangles, uint64_t ntriangles,
             } else {
                 uint32_t slot_index = (uint32_t) out.nodes.size();
                 out.nodes.emplace_back();
-                node.c[k].ref = slot_index;
+                node.c[k].ref = slot_index << RVB_BVH_NODE_SHIFT;     // byte offset of the child node
                 q.push({kids[k], slot_index, it.depth + 1});
             }
         }
@@ -384,7 +384,7 @@ std::string rvb_build_scene(const rvb_triangle * triangles, uint64_t ntriangles,
                 continue;
             ++nchild;
             if (!(c & RVB_BVH_LEAF))
-                deepest = std::max(deepest, need[c]);
+                deepest = std::max(deepest, need[c >> RVB_BVH_NODE_SHIFT]);
         }
         need[i] = (nchild ? nchild - 1 : 0) + deepest;
     }

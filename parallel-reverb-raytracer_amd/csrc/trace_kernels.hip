@@ -103,7 +103,7 @@ template <int K> __device__ __forceinline__ uint32_t quad_bcast_u(uint32_t v) { 
 // 4-bit mask of `pred` over this lane's quad
 __device__ __forceinline__ uint32_t quad_ballot(bool pred)
 {
-    const unsigned long long m = __ballot(pred);
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(pred);   // the condition mask itself, no 0/1 round trip through a VGPR
     return (uint32_t) (m >> (threadIdx.x & 60u)) & 0xFu;
 }
 
@@ -124,8 +124,14 @@ __device__ __forceinline__ bool slab(const uint4 n, const float ix, const float 
     const float tx0 = fmaf((float) h0.x, ix, -oix), tx1 = fmaf((float) h1.y, ix, -oix);
     const float ty0 = fmaf((float) h0.y, iy, -oiy), ty1 = fmaf((float) h2.x, iy, -oiy);
     const float tz0 = fmaf((float) h1.x, iz, -oiz), tz1 = fmaf((float) h2.y, iz, -oiz);
-    tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), neg_cull));
-    const float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), limit));
+    // The two folds with loop-invariant operands are written as instructions: fmaxf / fminf would first canonicalise
+    // `neg_cull` and `limit` (values from another basic block are not known to be quiet) — two more VALU operations per
+    // node step.  Neither is ever NaN; v_max / v_min return the other operand for a NaN box plane like fmaxf / fminf.
+    float zn = fminf(tz0, tz1), zf = fmaxf(tz0, tz1);
+    asm("v_max_f32 %0, %1, %2" : "=v"(zn) : "s"(neg_cull), "v"(zn));      // wave-uniform: stays in an SGPR
+    asm("v_min_f32 %0, %1, %2" : "=v"(zf) : "v"(zf), "v"(limit));
+    tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), zn);
+    const float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), zf);
     return tn <= tf && n.w != RVB_BVH_EMPTY;
 }
 
@@ -145,8 +151,9 @@ __device__ __forceinline__ void traverse_jobs(const SceneDev & sc, uint32_t * __
 {
     const uint32_t c = threadIdx.x & 3u;          // the child / leaf triangle this lane owns
     const uint32_t lane_base4 = (threadIdx.x & 60u) << 2;         // ds_bpermute address of the quad's lane 0
-    const uint32_t lt_mask = (1u << c) - 1u;
-    const char * node_base = reinterpret_cast<const char *>(sc.nodes) + 16u * c;
+    const uint32_t lane_bit = 1u << c, lt_mask = lane_bit - 1u;
+    const char * node_base = reinterpret_cast<const char *>(sc.nodes);   // wave-uniform: the load is base (SGPRs) + 32-bit lane offset
+    const uint32_t child_off = 16u * c;
     const float neg_cull = -sc.cull_abs, cull_scale = 1.0f + sc.cull_rel;
     v3 o = mk3(0, 0, 0), d = mk3(0, 0, 0);
     float tmax = 0.0f;
@@ -172,7 +179,7 @@ __device__ __forceinline__ void traverse_jobs(const SceneDev & sc, uint32_t * __
 #if RVB_STAMPS
             st.quad_node_steps += (threadIdx.x & 3u) == 0 ? 1 : 0;
 #endif
-            const uint4 n = *reinterpret_cast<const uint4 *>(node_base + ((size_t) ref << 6));
+            const uint4 n = *reinterpret_cast<const uint4 *>(node_base + (ref | child_off));
             const float limit = fmaf(best_t, cull_scale, sc.cull_abs);
             float tn;
             const bool ok = slab(n, ix, iy, iz, oix, oiy, oiz, limit, neg_cull, tn);
@@ -192,7 +199,11 @@ __device__ __forceinline__ void traverse_jobs(const SceneDev & sc, uint32_t * __
                 continue;
             }
             const uint32_t winner = kmin & 3u;
-            const uint32_t rest = quad_ballot(ok) & ~(1u << winner);
+            // the quad's hit mask by two DPP ORs (a 64-bit ballot shifted down per quad costs a 64-bit VALU shift)
+            uint32_t okmask = ok ? lane_bit : 0u;
+            okmask |= dpp_u<QP_SWAP1>(okmask);
+            okmask |= dpp_u<QP_SWAP2>(okmask);
+            const uint32_t rest = okmask & ~(1u << winner);
             if (ok && c != winner)
                 stack[(sp + __popc(rest & lt_mask)) * QUADS_PER_BLOCK] = cref;
             sp += __popc(rest);
@@ -299,7 +310,8 @@ __device__ __forceinline__ void traverse_jobs_vote(const SceneDev & sc, uint32_t
     const uint32_t c = threadIdx.x & 3u;
     const uint32_t lane_base4 = (threadIdx.x & 60u) << 2;
     const uint32_t lt_mask = (1u << c) - 1u;
-    const char * node_base = reinterpret_cast<const char *>(sc.nodes) + 16u * c;
+    const char * node_base = reinterpret_cast<const char *>(sc.nodes);   // wave-uniform: the load is base (SGPRs) + 32-bit lane offset
+    const uint32_t child_off = 16u * c;
     const float neg_cull = -sc.cull_abs, cull_scale = 1.0f + sc.cull_rel;
     v3 o = mk3(0, 0, 0), d = mk3(0, 0, 0);
     float tmax = 0.0f;
@@ -323,7 +335,7 @@ __device__ __forceinline__ void traverse_jobs_vote(const SceneDev & sc, uint32_t
             break;
         if (n_node >= n_leaf && n_node >= n_done) {
             if (at_node) {
-                const uint4 n = *reinterpret_cast<const uint4 *>(node_base + ((size_t) ref << 6));
+                const uint4 n = *reinterpret_cast<const uint4 *>(node_base + (ref | child_off));
                 const float limit = fmaf(best_t, cull_scale, sc.cull_abs);
                 float tn;
                 const bool ok = slab(n, ix, iy, iz, oix, oiy, oiz, limit, neg_cull, tn);
@@ -430,7 +442,7 @@ __device__ __forceinline__ bool traverse_lane(const SceneDev & sc, const v3 o, c
     uint32_t ref = 0;
     for (;;) {
         while (!(ref & RVB_BVH_LEAF)) {
-            const uint4 * n = reinterpret_cast<const uint4 *>(sc.nodes + ref);
+            const uint4 * n = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(sc.nodes) + ref);
             const float limit = fmaf(best_t, cull_scale, sc.cull_abs);
             float key[4];
             uint32_t cref[4];

@@ -96,7 +96,7 @@ struct Sim {
     void node_step(Query & q)
     {
         ++node_steps;
-        const BvhNode & n = bs.nodes[q.ref];
+        const BvhNode & n = bs.nodes[q.ref >> RVB_BVH_NODE_SHIFT];
         const float lim = limit(q), neg_cull = -cull_abs;
         bool ok[4]; float tn[4];
         int nok = 0;
