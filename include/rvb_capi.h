@@ -110,6 +110,11 @@ int rvb_merge_images(const rvb_image_candidate * candidates, uint64_t ncandidate
  * is all-zero give {0, 0} (the reference leaves them uninitialised, quirk Q2). */
 int rvb_attenuate_speaker(rvb_ctx * ctx, const float mic[3], const rvb_impulse * in, uint64_t n,
                           const rvb_speaker * speaker, rvb_attenuated_impulse * out);
+/* The same kernel on device-resident buffers (e.g. rvb_diffuse_device): d_in / d_out are HBM arrays of n Impulse /
+ * AttenuatedImpulse records, distinct.  Asynchronous on the context's stream; what SpeakerAttenuator::attenuate's
+ * per-channel re-upload of the impulse array (rayverb.cpp:863-875) becomes when the trace results never leave HBM. */
+int rvb_attenuate_speaker_device(rvb_ctx * ctx, const float mic[3], const void * d_in, uint64_t n,
+                                 const rvb_speaker * speaker, void * d_out);
 int rvb_attenuate_hrtf(rvb_ctx * ctx, const float mic[3], const rvb_impulse * in, uint64_t n,
                        const float * table /* [360*180*8] for this ear */,
                        const float facing[3], const float up[3], uint64_t channel,

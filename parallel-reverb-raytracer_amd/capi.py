@@ -26,7 +26,7 @@ SYMBOLS = [
     "rvb_create", "rvb_destroy", "rvb_last_error", "rvb_synchronize", "rvb_device_info",
     "rvb_set_scene", "rvb_scene_info", "rvb_set_directions", "rvb_set_directions_device", "rvb_trace",
     "rvb_get_diffuse", "rvb_diffuse_device", "rvb_get_direct", "rvb_get_image_candidates", "rvb_merge_images",
-    "rvb_attenuate_speaker", "rvb_attenuate_hrtf", "rvb_flatten",
+    "rvb_attenuate_speaker", "rvb_attenuate_speaker_device", "rvb_attenuate_hrtf", "rvb_flatten",
     "rvb_ir_configure_speakers", "rvb_ir_configure_hrtf", "rvb_ir_time_range", "rvb_ir_bins", "rvb_ir_accumulate",
     "rvb_ir_download", "rvb_last_timings", "rvb_debug_stamps", "rvb_executed_bounces",
 ]
@@ -220,6 +220,11 @@ class Context:
         out = np.zeros(imp.shape[0], dtype=ATTENUATED)
         self._check(self.lib.rvb_attenuate_speaker(self.handle, _f3(mic), _ptr(imp), _u64(imp.shape[0]), _ptr(sp), _ptr(out)))
         return out
+
+    def attenuate_speaker_device(self, mic, d_in, n, direction, coefficient, d_out):
+        """The materialised `attenuate` kernel on HBM-resident buffers (device addresses), asynchronous."""
+        sp = make_speakers([direction], [coefficient])
+        self._check(self.lib.rvb_attenuate_speaker_device(self.handle, _f3(mic), _vp(d_in), _u64(n), _ptr(sp), _vp(d_out)))
 
     def attenuate_hrtf(self, mic, impulses, table_channel, facing, up, channel):
         imp = np.ascontiguousarray(impulses, dtype=IMPULSE)

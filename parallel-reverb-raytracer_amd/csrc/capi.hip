@@ -566,6 +566,27 @@ int rvb_attenuate_speaker(rvb_ctx * ctx, const float mic[3], const rvb_impulse *
     return run_attenuate(ctx, m, 0, in, n, out);
 }
 
+int rvb_attenuate_speaker_device(rvb_ctx * ctx, const float mic[3], const void * d_in, uint64_t n,
+                                 const rvb_speaker * speaker, void * d_out)
+{
+    if (!ctx) return RVB_ERR_INVALID;
+    if (!mic || !speaker) return fail(ctx, RVB_ERR_INVALID, "rvb_attenuate_speaker_device: null argument");
+    if (n && (!d_in || !d_out)) return fail(ctx, RVB_ERR_INVALID, "rvb_attenuate_speaker_device: null buffer");
+    if (n && d_in == d_out) return fail(ctx, RVB_ERR_INVALID, "rvb_attenuate_speaker_device: in-place is not supported");
+    RVB_BIND(ctx);
+    AttenuationModel m;
+    m.hrtf = 0;
+    m.nchannels = 1;
+    for (int i = 0; i < 3; ++i) { m.mic[i] = mic[i]; m.speaker_dir[0][i] = speaker->direction[i]; }
+    m.speaker_coeff[0] = speaker->coefficient;
+    ctx->reset_timings();
+    ctx->begin_timing("attenuate_kernel");
+    rvb_launch_attenuate(m, 0, reinterpret_cast<const rvb_impulse *>(d_in), n, reinterpret_cast<rvb_attenuated_impulse *>(d_out), ctx->stream);
+    ctx->end_timing();
+    RVB_HIP(ctx, hipGetLastError());
+    return RVB_OK;
+}
+
 int rvb_attenuate_hrtf(rvb_ctx * ctx, const float mic[3], const rvb_impulse * in, uint64_t n,
                        const float * table, const float facing[3], const float up[3], uint64_t channel,
                        rvb_attenuated_impulse * out)

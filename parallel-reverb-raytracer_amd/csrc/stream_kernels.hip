@@ -10,6 +10,7 @@
 //     one per lane and one wave-wide float-atomic instruction adds 4 impulses x (2 channels x
 //     8 bands) = 4 x 64 contiguous bytes into the [bin][channel][band] accumulation image
 //     (memory-side atomics are paid per 64-byte request — MI355X_MICROARCH "Global float atomics").
+#include <cstdlib>
 #include <cstring>
 #include <string.h>
 
@@ -108,40 +109,97 @@ __device__ __forceinline__ uint32_t time_bin(float time, float predelay, float s
 }
 
 // ---- materialised attenuation: 4 lanes per impulse -------------------------------------------
+// DPP moves inside a quad (lanes 4k..4k+3): quad_perm broadcast of lane K, pair swaps
+template <int CTRL> __device__ __forceinline__ float qdpp_f(float v)
+{
+    return __uint_as_float((uint32_t) __builtin_amdgcn_mov_dpp((int) __float_as_uint(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL> __device__ __forceinline__ uint32_t qdpp_u(uint32_t v)
+{
+    return (uint32_t) __builtin_amdgcn_mov_dpp((int) v, CTRL, 0xF, 0xF, true);
+}
+#define QUAD_BCAST(k) ((k) * 0x55)
+#define QUAD_SWAP1 0xB1
+#define QUAD_SWAP2 0x4E
+#define ATT_UNROLL 1      // 16-byte chunks per lane per pass; with one workgroup per 4 KiB the dispatcher provides the parallelism
+
+// One 16-byte chunk of one impulse per lane: chunk 0/1 = volume, 2 = position, 3 = time.
+// Speaker model (kernel.cpp:505-535).  The two normalisations of kernel.cpp:511/:528 are three divisions each
+// by the same length: lane k of the quad divides component k, so a wave spends ONE correctly rounded division
+// per normalisation instead of three (same operations on the same operands: bit-identical results).
+__device__ __forceinline__ float4 attenuate_chunk_speaker(const ModelDev & m, uint32_t ch, uint32_t q, const float4 v)
+{
+    const float px = qdpp_f<QUAD_BCAST(2)>(v.x), py = qdpp_f<QUAD_BCAST(2)>(v.y), pz = qdpp_f<QUAD_BCAST(2)>(v.z);
+    const float time = qdpp_f<QUAD_BCAST(3)>(v.x);
+    uint32_t nz = (q < 2 && (v.x != 0.0f || v.y != 0.0f || v.z != 0.0f || v.w != 0.0f)) ? 1u : 0u;
+    nz |= qdpp_u<QUAD_SWAP1>(nz);
+    nz |= qdpp_u<QUAD_SWAP2>(nz);                                 // kernel.cpp:524 any(volume != 0)
+    float4 o = make_float4(0, 0, 0, 0);
+    if (nz) {
+        const v3 d = mk3(px, py, pz) - m.mic;                      // getDirection, kernel.cpp:528
+        const float len = length3(d);
+        const float own = q == 0 ? d.x : (q == 1 ? d.y : d.z);
+        const float n_own = len == 0.0f ? own : own / len;         // normalize3: a zero vector stays zero
+        const v3 n = mk3(qdpp_f<QUAD_BCAST(0)>(n_own), qdpp_f<QUAD_BCAST(1)>(n_own), qdpp_f<QUAD_BCAST(2)>(n_own));
+        const float len2 = length3(n);                             // kernel.cpp:511 normalises the unit vector again
+        const float u_own = len2 == 0.0f ? n_own : n_own / len2;
+        const v3 u = mk3(qdpp_f<QUAD_BCAST(0)>(u_own), qdpp_f<QUAD_BCAST(1)>(u_own), qdpp_f<QUAD_BCAST(2)>(u_own));
+        const float g = (1 - m.coeff[ch]) + m.coeff[ch] * dot3(u, m.sdir[ch]);
+        if (q < 2) o = make_float4(v.x * g, v.y * g, v.z * g, v.w * g);
+        else if (q == 2) o.x = time;
+    }
+    return o;
+}
+
+// HRTF model (kernel.cpp:586-625): table row by azimuth / elevation, per-ear arrival-time shift
+__device__ __forceinline__ float4 attenuate_chunk_hrtf(const ModelDev & m, uint32_t ch, uint32_t q, const float4 v)
+{
+    const float px = qdpp_f<QUAD_BCAST(2)>(v.x), py = qdpp_f<QUAD_BCAST(2)>(v.y), pz = qdpp_f<QUAD_BCAST(2)>(v.z);
+    const float time = qdpp_f<QUAD_BCAST(3)>(v.x);
+    uint32_t nz = (q < 2 && (v.x != 0.0f || v.y != 0.0f || v.z != 0.0f || v.w != 0.0f)) ? 1u : 0u;
+    nz |= qdpp_u<QUAD_SWAP1>(nz);
+    nz |= qdpp_u<QUAD_SWAP2>(nz);                                 // kernel.cpp:607
+    float4 o = make_float4(0, 0, 0, 0);
+    if (nz) {
+        const v3 pos = mk3(px, py, pz);
+        const int64_t row = hrtf_row(m, pos);
+        if (q < 2) {
+            const float4 t = reinterpret_cast<const float4 *>(m.table + ((uint64_t) ch * (360 * 180 + 1) + (uint64_t) row) * 8)[q];
+            o = make_float4(v.x * t.x, v.y * t.y, v.z * t.z, v.w * t.w);
+        } else if (q == 2) {
+            o.x = hrtf_time(m, ch, pos, time);
+        }
+    }
+    return o;
+}
+
+template <bool HRTF>
 __global__ __launch_bounds__(256) void attenuate_kernel(ModelDev m, uint32_t ch, const float4 * __restrict__ in,
                                                         float4 * __restrict__ out, uint64_t n)
 {
     const uint32_t q = threadIdx.x & 3u;
-    const uint64_t nchunks = n * 4;
-    for (uint64_t c = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; c < ((nchunks + 63) & ~63ull);
-         c += (uint64_t) gridDim.x * blockDim.x) {
-        const bool live = c < nchunks;
-        float4 v = live ? in[c] : make_float4(0, 0, 0, 0);
-        // chunk 2 = position, chunk 3 = time; quad lanes 0/1 hold the volumes
-        const int base = (int) (threadIdx.x & 63u & ~3u);
-        const float px = __shfl(v.x, base + 2), py = __shfl(v.y, base + 2), pz = __shfl(v.z, base + 2);
-        const float time = __shfl(v.x, base + 3);
-        const bool nz_local = q < 2 && (v.x != 0.0f || v.y != 0.0f || v.z != 0.0f || v.w != 0.0f);
-        const unsigned long long mask = __ballot(nz_local);
-        const bool nonzero = ((mask >> base) & 3ull) != 0;      // kernel.cpp:524 / :607 any(volume != 0)
-        float4 o = make_float4(0, 0, 0, 0);
-        if (nonzero) {
-            const v3 pos = mk3(px, py, pz);
-            if (!m.hrtf) {
-                const float g = speaker_gain(m, ch, pos);
-                if (q < 2) o = make_float4(v.x * g, v.y * g, v.z * g, v.w * g);
-                else if (q == 2) o.x = time;
-            } else {
-                const int64_t row = hrtf_row(m, pos);
-                if (q < 2) {
-                    const float4 t = reinterpret_cast<const float4 *>(m.table + ((uint64_t) ch * (360 * 180 + 1) + (uint64_t) row) * 8)[q];
-                    o = make_float4(v.x * t.x, v.y * t.y, v.z * t.z, v.w * t.w);
-                } else if (q == 2) {
-                    o.x = hrtf_time(m, ch, pos, time);
-                }
+    const uint64_t nchunks = n * 4;                                // whole quads: a quad's four chunks are live together
+    const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
+    for (uint64_t c0 = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; c0 < nchunks; c0 += stride * ATT_UNROLL) {
+        float4 v[ATT_UNROLL];
+#pragma unroll
+        for (int u = 0; u < ATT_UNROLL; ++u) {                    // all loads leave before the first result is needed
+            const uint64_t c = c0 + (uint64_t) u * stride;
+            v[u] = make_float4(0, 0, 0, 0);
+            if (c < nchunks) {
+                const nt_float4_t t = __builtin_nontemporal_load(reinterpret_cast<const nt_float4_t *>(in + c));
+                v[u] = make_float4(t.x, t.y, t.z, t.w);
             }
         }
-        if (live) out[c] = o;
+#pragma unroll
+        for (int u = 0; u < ATT_UNROLL; ++u) {
+            const uint64_t c = c0 + (uint64_t) u * stride;
+            if (c < nchunks) {
+                const float4 o = HRTF ? attenuate_chunk_hrtf(m, ch, q, v[u]) : attenuate_chunk_speaker(m, ch, q, v[u]);
+                const nt_float4_t t = {o.x, o.y, o.z, o.w};
+                __builtin_nontemporal_store(t, reinterpret_cast<nt_float4_t *>(out + c));
+            }
+        }
     }
 }
 
@@ -405,10 +463,15 @@ __global__ __launch_bounds__(64) void flat_ordered_sum_kernel(const rvb_attenuat
         out[(uint64_t) b * nbins + bin] = sum[b];
 }
 
+// Workgroups for a streaming kernel of `items` work-items.  NOT capped at a few workgroups per CU: measured on MI355X
+// (tools/copy_probe.hip, 819 MB -> 819 MB, 16 B per lane) a grid-strided 2048-workgroup launch moves 4.5-5.3 TB/s, one
+// workgroup per 4 KiB moves 6.1-6.5 TB/s — the dispatcher then sweeps HBM as one moving window instead of 2048 streams
+// 8 MB apart.  The kernels keep their grid-stride loops for the (never reached in practice) 2^31-workgroup limit.
 unsigned stream_blocks(uint64_t items, unsigned per_block)
 {
+    static const uint64_t cap = getenv("RVB_STREAM_BLOCK_CAP") ? strtoull(getenv("RVB_STREAM_BLOCK_CAP"), nullptr, 10) : 0x7FFFFFFFull;
     uint64_t blocks = (items + per_block - 1) / per_block;
-    if (blocks > 256u * 8u) blocks = 256u * 8u;       // 8 workgroups per CU, grid-stride the rest
+    if (blocks > cap) blocks = cap;
     return (unsigned) (blocks ? blocks : 1);
 }
 
@@ -418,8 +481,13 @@ void rvb_launch_attenuate(const AttenuationModel & m, uint32_t channel, const rv
                           rvb_attenuated_impulse * out, hipStream_t s)
 {
     if (n == 0) return;
-    hipLaunchKernelGGL(attenuate_kernel, dim3(stream_blocks(n * 4, 256)), dim3(256), 0, s, make_model(m), channel,
-                       reinterpret_cast<const float4 *>(in), reinterpret_cast<float4 *>(out), n);
+    const dim3 grid(stream_blocks((n * 4 + ATT_UNROLL - 1) / ATT_UNROLL, 256));
+    if (m.hrtf)
+        hipLaunchKernelGGL(attenuate_kernel<true>, grid, dim3(256), 0, s, make_model(m), channel,
+                           reinterpret_cast<const float4 *>(in), reinterpret_cast<float4 *>(out), n);
+    else
+        hipLaunchKernelGGL(attenuate_kernel<false>, grid, dim3(256), 0, s, make_model(m), channel,
+                           reinterpret_cast<const float4 *>(in), reinterpret_cast<float4 *>(out), n);
 }
 
 void rvb_launch_time_range(const AttenuationModel & m, const rvb_impulse * in, uint64_t n, uint32_t * range, hipStream_t s)
