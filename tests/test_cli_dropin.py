@@ -23,10 +23,10 @@ INC = ["-I" + os.path.join(ROOT, "include", "rayverb"), "-I" + os.path.join(ROOT
 LINK = ["-L" + PKG, "-lrayverb", "-lrvb_hip", "-Wl,-rpath," + PKG]
 
 
-def _compile(src, out, std="-std=c++11"):
+def _compile(src, out, std="-std=c++11", extra=()):
     subprocess.check_call(["make", "-C", PKG, "-j4"], stdout=subprocess.DEVNULL)
     os.makedirs(BUILD, exist_ok=True)
-    subprocess.check_call(["g++", std, "-O1", "-w"] + INC + [src, "-o", out] + LINK)
+    subprocess.check_call(["g++", std, "-O1", "-w"] + list(extra) + INC + [src, "-o", out] + LINK)
     return out
 
 
@@ -43,6 +43,13 @@ def test_reference_cli_compiles_unchanged_and_fails_like_the_reference_without_g
     args[1] = assets + "/configs/tunnel.json"
     r = subprocess.run(args, capture_output=True, text=True)
     assert r.returncode == 1 and "invalid value" in r.stderr
+
+
+@pytest.mark.skipif(not os.path.exists(REFERENCE_CLI), reason="reference checkout not present (GPU box)")
+def test_reference_cli_diagnostic_build_links(tmp_path):
+    """-DDIAGNOSTIC makes cmd/main.cpp:270-278 call print_diagnostic (the impulse.dump writer, helpers.cpp:19-59)."""
+    exe = _compile(REFERENCE_CLI, str(tmp_path / "parallel_raytrace_diag"), std="-std=c++1y", extra=["-DDIAGNOSTIC"])
+    assert os.path.exists(exe)
 
 
 # ---- independent restatement of the post-processing chain ---------------------------------------------
