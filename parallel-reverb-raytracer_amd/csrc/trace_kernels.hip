@@ -26,7 +26,7 @@
 #include <cstdlib>
 
 #ifndef RVB_PATH_JOBS
-#define RVB_PATH_JOBS 1
+#define RVB_PATH_JOBS 2     // 2: majority-vote job loop (traverse_jobs_vote), 1: while-while job loop, 0: one query at a time
 #endif
 #ifndef RVB_SHADOW_JOBS
 #define RVB_SHADOW_JOBS 0
@@ -94,6 +94,10 @@ template <int CTRL> __device__ __forceinline__ uint32_t dpp_u(uint32_t v)
     return (uint32_t) __builtin_amdgcn_mov_dpp((int) v, CTRL, 0xF, 0xF, true);
 }
 template <int CTRL> __device__ __forceinline__ float dpp_f(float v) { return __uint_as_float(dpp_u<CTRL>(__float_as_uint(v))); }
+template <int CTRL> __device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v)
+{
+    return ((unsigned long long) dpp_u<CTRL>((uint32_t) (v >> 32)) << 32) | dpp_u<CTRL>((uint32_t) v);
+}
 #define QP_SWAP1 0xB1     // quad_perm [1,0,3,2]
 #define QP_SWAP2 0x4E     // quad_perm [2,3,0,1]
 #define QP_BCAST(k) ((k) * 0x55)
@@ -296,47 +300,58 @@ __device__ __forceinline__ void traverse_jobs(const SceneDev & sc, uint32_t * __
 #undef RVB_RESET_QUERY
 }
 
-// Closest-hit job loop with a per-iteration MAJORITY VOTE over the wave's 16 quads (path_kernel).
-// A quad is in one of three states: at a node, at a leaf, or done with its query.  The while-while loop above
-// runs node steps until the LAST quad has reached a leaf, so on incoherent rays (every bounce after the first)
-// only ~7 of 16 quads do useful work in a node step.  Here every iteration executes ONE step kind — the one most
-// quads are waiting for (ties: the cheaper kind) — for the quads in that state; the others keep their state.
-// Host replay of this policy on workload C2 (tools/travsim.cpp): wave-level node steps per bounce 37 -> 28,
-// quads active per node step 6.7 -> 8.9, wave instructions per bounce -14 %.  The votes are three ballots and
-// scalar popcounts per iteration.
+// Population count of a wave mask as a 32-bit scalar (the builtin's 64-bit result drags the comparisons that follow
+// onto the VALU as 64-bit compares).
+__device__ __forceinline__ int scalar_popcount(unsigned long long mask)
+{
+    int n;
+    asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n) : "s"(mask) : "scc");
+    return n;
+}
+
+// Closest-hit job loop with a per-iteration MAJORITY VOTE over the wave's 16 quads (path_kernel, RVB_PATH_JOBS=2).
+// A quad is in one of four states, all encoded in `ref`: at a node (bit 31 clear), at a leaf (bit 31 set), query
+// finished (NONE), out of jobs (IDLE).  The while-while loop above runs node steps until the LAST quad has reached a
+// leaf, so on incoherent rays (every bounce after the first) only ~7 of 16 quads do useful work in a node step.  Here
+// every iteration executes ONE step kind — the one most quads are waiting for (ties: the cheaper kind) — for the
+// quads in that state; the others keep their state.  Host replay on workload C2 (tools/travsim.cpp): wave-level node
+// steps per bounce 37 -> 28, quads active per node step 6.7 -> 8.9, wave instructions per bounce -13 % before the
+// vote's own cost: three compares into SGPR masks and scalar popcounts per iteration.
 template <class Job>
 __device__ __forceinline__ void traverse_jobs_vote(const SceneDev & sc, uint32_t * __restrict__ stack, Job & job)
 {
+    const uint32_t IDLE = 0xFFFFFFFEu;
     const uint32_t c = threadIdx.x & 3u;
     const uint32_t lane_base4 = (threadIdx.x & 60u) << 2;
-    const uint32_t lt_mask = (1u << c) - 1u;
-    const char * node_base = reinterpret_cast<const char *>(sc.nodes);   // wave-uniform: the load is base (SGPRs) + 32-bit lane offset
+    const uint32_t lane_bit = 1u << c, lt_mask = lane_bit - 1u;
+    const char * node_base = reinterpret_cast<const char *>(sc.nodes);
     const uint32_t child_off = 16u * c;
     const float neg_cull = -sc.cull_abs, cull_scale = 1.0f + sc.cull_rel;
     v3 o = mk3(0, 0, 0), d = mk3(0, 0, 0);
     float tmax = 0.0f;
-    float ix = 0.0f, iy = 0.0f, iz = 0.0f, oix = 0.0f, oiy = 0.0f, oiz = 0.0f, best_t = 0.0f;
-    uint32_t best_i = NONE, sp = 0, ref = 0;
-    bool active = job.next(o, d, tmax);
+    const unsigned long long NO_HIT_KEY = (0x7F800000ull << 32) | NONE;
+    const char * tri_base = reinterpret_cast<const char *>(sc.tris);      // wave-uniform base + 32-bit byte offset, like the nodes
+    float ix = 0.0f, iy = 0.0f, iz = 0.0f, oix = 0.0f, oiy = 0.0f, oiz = 0.0f;
+    unsigned long long best_key = NO_HIT_KEY;                              // (distance bits, triangle index) of the closest hit so far
+    uint32_t sp = 0, ref = IDLE;
 #define RVB_RESET_QUERY()                                                         \
     {                                                                             \
         ix = clamp_inv(d.x); iy = clamp_inv(d.y); iz = clamp_inv(d.z);            \
         oix = o.x * ix; oiy = o.y * iy; oiz = o.z * iz;                           \
-        best_t = __builtin_inff();                                                \
-        best_i = NONE; sp = 0; ref = 0;                                           \
+        best_key = NO_HIT_KEY; sp = 0; ref = 0;                                   \
     }
-    if (active) RVB_RESET_QUERY()
+    if (job.next(o, d, tmax)) RVB_RESET_QUERY()
     for (;;) {
-        const bool at_node = active && !(ref & RVB_BVH_LEAF);
-        const bool at_leaf = active && (ref & RVB_BVH_LEAF) && ref != NONE;
-        const bool at_done = active && ref == NONE;
-        const int n_node = __popcll(__ballot(at_node)), n_leaf = __popcll(__ballot(at_leaf)), n_done = __popcll(__ballot(at_done));
-        if (n_node + n_leaf + n_done == 0)
+        const unsigned long long m_node = __builtin_amdgcn_ballot_w64((int32_t) ref >= 0);
+        const unsigned long long m_done = __builtin_amdgcn_ballot_w64(ref == NONE);
+        const unsigned long long m_leaf = __builtin_amdgcn_ballot_w64((int32_t) ref < (int32_t) IDLE);   // signed: leaves are < -2
+        const int n_node = scalar_popcount(m_node), n_done = scalar_popcount(m_done), n_leaf = scalar_popcount(m_leaf);
+        if ((n_node | n_done | n_leaf) == 0)
             break;
         if (n_node >= n_leaf && n_node >= n_done) {
-            if (at_node) {
+            if ((int32_t) ref >= 0) {
                 const uint4 n = *reinterpret_cast<const uint4 *>(node_base + (ref | child_off));
-                const float limit = fmaf(best_t, cull_scale, sc.cull_abs);
+                const float limit = fmaf(__uint_as_float((uint32_t) (best_key >> 32)), cull_scale, sc.cull_abs);
                 float tn;
                 const bool ok = slab(n, ix, iy, iz, oix, oiy, oiz, limit, neg_cull, tn);
                 const uint32_t cref = n.w;
@@ -347,7 +362,10 @@ __device__ __forceinline__ void traverse_jobs_vote(const SceneDev & sc, uint32_t
                     if (sp > 0) { --sp; ref = stack[sp * QUADS_PER_BLOCK]; } else ref = NONE;
                 } else {
                     const uint32_t winner = kmin & 3u;
-                    const uint32_t rest = quad_ballot(ok) & ~(1u << winner);
+                    uint32_t okmask = ok ? lane_bit : 0u;
+                    okmask |= dpp_u<QP_SWAP1>(okmask);
+                    okmask |= dpp_u<QP_SWAP2>(okmask);
+                    const uint32_t rest = okmask & ~(1u << winner);
                     if (ok && c != winner)
                         stack[(sp + __popc(rest & lt_mask)) * QUADS_PER_BLOCK] = cref;
                     sp += __popc(rest);
@@ -355,46 +373,37 @@ __device__ __forceinline__ void traverse_jobs_vote(const SceneDev & sc, uint32_t
                 }
             }
         } else if (n_leaf >= n_done) {
-            if (at_leaf) {
+            if ((int32_t) ref < (int32_t) IDLE) {
                 const uint32_t first = ref & 0x0FFFFFFFu;
                 const uint32_t count = ((ref >> 28) & 7u) + 1u;
                 float dist = 0.0f;
                 uint32_t idx = NONE;
                 if (c < count) {
-                    const float4 * tp = reinterpret_cast<const float4 *>(sc.tris + first + c);
+                    const float4 * tp = reinterpret_cast<const float4 *>(tri_base + (first + c) * (uint32_t) sizeof(BvhTri));
                     float4 ta = tp[0], tb = tp[1], tc = tp[2];
                     asm volatile("" : "+v"(ta.x), "+v"(tb.x), "+v"(tc.x));     // all three loads leave before the first use
                     dist = mt_intersect(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), o, d);
                     idx = __float_as_uint(tc.y);
                 }
-                // kernel.cpp:180-188 — smallest distance wins, equal distances go to the lower index
+                // kernel.cpp:180-188 — smallest distance wins, equal distances go to the lower index.  A candidate
+                // distance is > EPSILON > 0, and positive floats order like their bit patterns, so (distance, index)
+                // is ONE unsigned 64-bit key: the quad minimum and the comparison with the best so far are three
+                // 64-bit compares.  "No hit" is (+inf, NONE), the largest key a lane can hold.
                 const bool valid = c < count && dist > RVB_EPSILON;
-                float rd = valid ? dist : __builtin_inff();
-                uint32_t ri = valid ? idx : NONE;
-                {
-                    const float od = dpp_f<QP_SWAP1>(rd);
-                    const uint32_t oi = dpp_u<QP_SWAP1>(ri);
-                    if (od < rd || (od == rd && oi < ri)) { rd = od; ri = oi; }
-                }
-                {
-                    const float od = dpp_f<QP_SWAP2>(rd);
-                    const uint32_t oi = dpp_u<QP_SWAP2>(ri);
-                    if (od < rd || (od == rd && oi < ri)) { rd = od; ri = oi; }
-                }
-                if (ri != NONE && (best_i == NONE || rd < best_t || (rd == best_t && ri < best_i))) {
-                    best_t = rd;
-                    best_i = ri;
-                }
+                unsigned long long key = valid ? (((unsigned long long) __float_as_uint(dist) << 32) | idx) : NO_HIT_KEY;
+                key = min(key, dpp_u64<QP_SWAP1>(key));
+                key = min(key, dpp_u64<QP_SWAP2>(key));
+                best_key = min(best_key, key);
                 if (sp > 0) { --sp; ref = stack[sp * QUADS_PER_BLOCK]; } else ref = NONE;
             }
         } else {
-            if (at_done) {
+            if (ref == NONE) {
                 Hit h;
-                h.t = best_t;
-                h.tri = best_i;
-                job.done(best_i != NONE, h);
-                active = job.next(o, d, tmax);
-                if (active) RVB_RESET_QUERY()
+                h.t = __uint_as_float((uint32_t) (best_key >> 32));
+                h.tri = (uint32_t) best_key;
+                job.done(h.tri != NONE, h);
+                ref = IDLE;
+                if (job.next(o, d, tmax)) RVB_RESET_QUERY()
             }
         }
     }
@@ -524,14 +533,13 @@ __device__ __forceinline__ const float4 * stage_surfaces(const TraceArgs & a, ui
 
 struct PathJob {
     const TraceArgs & a;
-    uint64_t ray;
+    uint32_t ray;                        // < 2^32 / 9 (rvb_trace checks)
     uint32_t c;
     v3 o, d;
     float distance;
-    float vol[8];
+    float4 vol;                          // lane 0 (and 2): bands 0-3, lane 1 (and 3): bands 4-7 — the chunk the lane stores
     uint32_t index;
     bool alive;
-    float4 * out;
     const float4 * surf_lds;             // the surface table staged in LDS (stage_surfaces), or null: read it from HBM
 
     __device__ __forceinline__ bool next(v3 & o_, v3 & d_, float & tmax)
@@ -553,29 +561,23 @@ struct PathJob {
         const v3 normal = mk3(sh.x, sh.y, sh.z);
         const uint32_t surface = __float_as_uint(sh.w);
         // the specular row hangs off a dependent load (triangle -> surface -> row): from LDS it costs ~64 cycles
-        // instead of another L2 round trip in the middle of the ray's latency chain
-        float4 s0, s1;
-        if (surf_lds) {
-            s0 = surf_lds[4 * surface]; s1 = surf_lds[4 * surface + 1];
-        } else {
-            const float4 * sp = reinterpret_cast<const float4 *>(a.scene.surfaces + surface);
-            s0 = sp[0]; s1 = sp[1];
-        }
+        // instead of another L2 round trip; each lane reads the half row of the four bands it carries
+        const uint32_t half = c & 1u;
+        const float4 sp = surf_lds ? surf_lds[4 * surface + half]
+                                   : reinterpret_cast<const float4 *>(a.scene.surfaces + surface)[half];
         const v3 p = o + d * h.t;                                    // kernel.cpp:459
         const float new_dist = distance + h.t;                       // kernel.cpp:460
-        vol[0] = -vol[0] * s0.x; vol[1] = -vol[1] * s0.y; vol[2] = -vol[2] * s0.z; vol[3] = -vol[3] * s0.w;
-        vol[4] = -vol[4] * s1.x; vol[5] = -vol[5] * s1.y; vol[6] = -vol[6] * s1.z; vol[7] = -vol[7] * s1.w;
+        vol = make_float4(-vol.x * sp.x, -vol.y * sp.y, -vol.z * sp.z, -vol.w * sp.w);   // kernel.cpp:461
         const float diff = fabsf(dot3(normal, d));                   // kernel.cpp:478
-        float4 chunk;
-        if (c == 0) chunk = make_float4(vol[0], vol[1], vol[2], vol[3]);
-        else if (c == 1) chunk = make_float4(vol[4], vol[5], vol[6], vol[7]);
-        else if (c == 2) chunk = make_float4(p.x, p.y, p.z, diff);
-        else chunk = make_float4(new_dist, __uint_as_float(surface), __uint_as_float(h.tri), __uint_as_float(1u));
-        store_stream(out + 4 * index + c, chunk);
+        float4 chunk = vol;
+        if (c == 2) chunk = make_float4(p.x, p.y, p.z, diff);
+        else if (c == 3) chunk = make_float4(new_dist, __uint_as_float(surface), __uint_as_float(h.tri), __uint_as_float(1u));
+        const uint64_t record = (uint64_t) ray * a.nreflections + index;
+        store_stream(reinterpret_cast<float4 *>(a.impulses + record) + c, chunk);
         if (c == 0 && index < RVB_NUM_IMAGE_SOURCE - 1)
             a.early[ray * (RVB_NUM_IMAGE_SOURCE - 1) + index] = h.tri;
         if (c == 1 && a.sort_keys)
-            a.sort_keys[ray * a.nreflections + index] = a.scene.leafpos[h.tri];
+            a.sort_keys[record] = a.scene.leafpos[h.tri];
         d = reflect3(normal, d);                                     // kernel.cpp:492-499
         o = p;
         distance = new_dist;
@@ -583,7 +585,9 @@ struct PathJob {
     }
 };
 
-__global__ __launch_bounds__(WAVE, 7) void path_kernel(TraceArgs a)
+// 64 VGPRs = 8 waves per SIMD: one resident round holds 8 x 1024 x 16 = 131 072 rays, so the 125 k rays per GPU of
+// workload C3 still run as one round (at 72 VGPRs / 7 waves they took 5.1 ms instead of 4.3 ms).
+__global__ __launch_bounds__(WAVE, 8) void path_kernel(TraceArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t stack_lds[];   // [stack_entries][QUADS_PER_BLOCK]
     const uint32_t q = threadIdx.x >> 2;
@@ -592,9 +596,8 @@ __global__ __launch_bounds__(WAVE, 7) void path_kernel(TraceArgs a)
     if (ray >= a.nrays)
         return;                                   // whole quads leave together
     const float4 d4 = a.directions[ray];
-    PathJob job = {a, ray, threadIdx.x & 3u, ld3(a.source), mk3(d4.x, d4.y, d4.z), 0.0f,
-                   {1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f}, 0u, true,
-                   reinterpret_cast<float4 *>(a.impulses + ray * a.nreflections), surf_lds};
+    PathJob job = {a, (uint32_t) ray, threadIdx.x & 3u, ld3(a.source), mk3(d4.x, d4.y, d4.z), 0.0f,
+                   make_float4(1.0f, 1.0f, 1.0f, 1.0f), 0u, true, surf_lds};
 #if RVB_PATH_JOBS == 2
     traverse_jobs_vote(a.scene, stack_lds + q, job);
 #elif RVB_PATH_JOBS
@@ -611,9 +614,10 @@ __global__ __launch_bounds__(WAVE, 7) void path_kernel(TraceArgs a)
     // An escaped ray leaves its remaining slots zero-filled (reference rayverb.cpp:600-603 zero-fills the
     // whole buffer before every launch; here only the few slots that need it are written).
     for (uint32_t i = job.index; i < a.nreflections; ++i) {
-        store_stream(job.out + 4 * i + job.c, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+        const uint64_t record = ray * a.nreflections + i;
+        store_stream(reinterpret_cast<float4 *>(a.impulses + record) + job.c, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
         if (job.c == 1 && a.sort_keys)
-            a.sort_keys[ray * a.nreflections + i] = NONE;
+            a.sort_keys[record] = NONE;
     }
     if (job.c == 0)
         atomicAdd(a.executed, (unsigned long long) job.index);
@@ -877,9 +881,9 @@ static size_t quad_kernel_lds_bytes(const TraceArgs & a)
 
 uint32_t rvb_lds_surfaces(uint32_t stack_entries, uint64_t nsurfaces)
 {
-    // 7 waves/SIMD = 28 single-wave workgroups per CU must still fit in the CU's 160 KiB of LDS
+    // 8 waves/SIMD = 32 single-wave workgroups per CU must still fit in the CU's 160 KiB of LDS
     static const bool off = getenv("RVB_LDS_SURFACES") && getenv("RVB_LDS_SURFACES")[0] == '0';
-    const size_t budget = (160u * 1024u) / 28u;
+    const size_t budget = (160u * 1024u) / 32u;
     const size_t stack = (size_t) stack_entries * QUADS_PER_BLOCK * sizeof(uint32_t);
     if (off || nsurfaces == 0 || stack + nsurfaces * sizeof(rvb_surface) > budget)
         return 0;

@@ -167,8 +167,8 @@ int main(int argc, char ** argv)
     printf("nodes %zu tris %zu depth %u stack_need %u\n", base.bs.nodes.size(), base.bs.tris.size(), base.bs.depth, base.bs.stack_need);
     const float * dirs = (const float *) db.data();
 
-    const double C_NODE = 48, C_LEAF = 120, C_DONE = 110;        // wave instructions per step (from the ISA)
-    for (int p = 0; p < 6; ++p) {
+    const double C_NODE = 57, C_LEAF = 160, C_DONE = 150;        // wave instructions per step (from the ISA)
+    for (int p = 0; p < 14; ++p) {
         Sim s = base;
         s.pol.stack_dist = 0; s.pol.sorted_push = 0; s.pol.postpone = 0;
         // scheduler: 0 = while-while (shipped); 1 = majority vote; 2..: node loop runs while >= T quads want a node step
@@ -212,10 +212,11 @@ int main(int argc, char ** argv)
                     if (sl > best) { act = LEAF; best = sl; }
                     if (sd > best) { act = DONE; best = sd; }
                 } else {
-                    if (cn >= T || (cl == 0 && cd == 0)) act = NODE;
-                    else if (cl >= cd && cl) act = LEAF;
-                    else if (cd) act = DONE;
-                    else act = LEAF;
+                    // while-while, but the done step waits until K quads are pending (or nothing else can run)
+                    const int K = sched - 5;
+                    if (phase == 0) { if (cn) act = NODE; else { phase = 1; continue; } }
+                    else if (phase == 1) { phase = 2; if (cl) act = LEAF; else continue; }
+                    else { phase = 0; if (cd >= K || (cd && cn + cl == 0)) act = DONE; else continue; }
                 }
                 if (act == NODE) {
                     ++w_node; q_node_active += cn;
