@@ -519,7 +519,13 @@ __device__ __forceinline__ v3 ld3(const float * p) { return mk3(p[0], p[1], p[2]
 // Copies the scene's surface table (64 B per surface) behind the traversal stack in LDS when the launch reserved
 // room for it (TraceArgs::lds_surfaces = number of surfaces staged, 0 = none).  Single-wave workgroups: the
 // barrier is only the wait for the wave's own LDS writes.
-__device__ __forceinline__ const float4 * stage_surfaces(const TraceArgs & a, uint32_t * lds_after_stack)
+typedef __attribute__((address_space(3))) const nt_float4 * lds_float4_ptr;  // keeps ds_read: a generic pointer would load flat
+__device__ __forceinline__ float4 lds_load4(lds_float4_ptr p, uint32_t i)
+{
+    const nt_float4 t = p[i];
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ lds_float4_ptr stage_surfaces(const TraceArgs & a, uint32_t * lds_after_stack)
 {
     if (!a.lds_surfaces)
         return nullptr;
@@ -528,9 +534,10 @@ __device__ __forceinline__ const float4 * stage_surfaces(const TraceArgs & a, ui
     for (uint32_t i = threadIdx.x; i < 4u * a.lds_surfaces; i += WAVE)
         dst[i] = src[i];
     __syncthreads();
-    return dst;
+    return (lds_float4_ptr) dst;
 }
 
+template <bool SURF_LDS>
 struct PathJob {
     const TraceArgs & a;
     uint32_t ray;                        // < 2^32 / 9 (rvb_trace checks)
@@ -540,7 +547,7 @@ struct PathJob {
     float4 vol;                          // lane 0 (and 2): bands 0-3, lane 1 (and 3): bands 4-7 — the chunk the lane stores
     uint32_t index;
     bool alive;
-    const float4 * surf_lds;             // the surface table staged in LDS (stage_surfaces), or null: read it from HBM
+    lds_float4_ptr surf_lds;             // the surface table staged in LDS (stage_surfaces); unused when !SURF_LDS
 
     __device__ __forceinline__ bool next(v3 & o_, v3 & d_, float & tmax)
     {
@@ -563,8 +570,9 @@ struct PathJob {
         // the specular row hangs off a dependent load (triangle -> surface -> row): from LDS it costs ~64 cycles
         // instead of another L2 round trip; each lane reads the half row of the four bands it carries
         const uint32_t half = c & 1u;
-        const float4 sp = surf_lds ? surf_lds[4 * surface + half]
-                                   : reinterpret_cast<const float4 *>(a.scene.surfaces + surface)[half];
+        float4 sp;
+        if (SURF_LDS) sp = lds_load4(surf_lds, 4 * surface + half);
+        else sp = reinterpret_cast<const float4 *>(a.scene.surfaces + surface)[half];
         const v3 p = o + d * h.t;                                    // kernel.cpp:459
         const float new_dist = distance + h.t;                       // kernel.cpp:460
         vol = make_float4(-vol.x * sp.x, -vol.y * sp.y, -vol.z * sp.z, -vol.w * sp.w);   // kernel.cpp:461
@@ -587,16 +595,17 @@ struct PathJob {
 
 // 64 VGPRs = 8 waves per SIMD: one resident round holds 8 x 1024 x 16 = 131 072 rays, so the 125 k rays per GPU of
 // workload C3 still run as one round (at 72 VGPRs / 7 waves they took 5.1 ms instead of 4.3 ms).
+template <bool SURF_LDS>
 __global__ __launch_bounds__(WAVE, 8) void path_kernel(TraceArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t stack_lds[];   // [stack_entries][QUADS_PER_BLOCK]
     const uint32_t q = threadIdx.x >> 2;
     const uint64_t ray = (uint64_t) blockIdx.x * QUADS_PER_BLOCK + q;
-    const float4 * surf_lds = stage_surfaces(a, stack_lds + a.stack_entries * QUADS_PER_BLOCK);
+    const lds_float4_ptr surf_lds = stage_surfaces(a, stack_lds + a.stack_entries * QUADS_PER_BLOCK);
     if (ray >= a.nrays)
         return;                                   // whole quads leave together
     const float4 d4 = a.directions[ray];
-    PathJob job = {a, (uint32_t) ray, threadIdx.x & 3u, ld3(a.source), mk3(d4.x, d4.y, d4.z), 0.0f,
+    PathJob<SURF_LDS> job = {a, (uint32_t) ray, threadIdx.x & 3u, ld3(a.source), mk3(d4.x, d4.y, d4.z), 0.0f,
                    make_float4(1.0f, 1.0f, 1.0f, 1.0f), 0u, true, surf_lds};
 #if RVB_PATH_JOBS == 2
     traverse_jobs_vote(a.scene, stack_lds + q, job);
@@ -754,6 +763,7 @@ __global__ __launch_bounds__(WAVE) void image_kernel(TraceArgs a)
 // The shadow rays as Jobs: a quad walks the work records g, g + stride, ...; next() loads a record
 // (the quad reads its 64 bytes as one line, lane c = chunk c) and aims at the microphone
 // (kernel.cpp:463-469), done() finishes the Impulse in place (kernel.cpp:471-490).
+template <bool SURF_LDS>
 struct ShadowJob {
     const TraceArgs & a;
     uint32_t c;
@@ -766,7 +776,7 @@ struct ShadowJob {
     float diff, new_dist, mag;
     uint32_t surface;
     float tmin, tmax_seen;               // arrival-time range of the non-zero impulses this lane's quad produced
-    const float4 * surf_lds;             // surface table in LDS, or null
+    lds_float4_ptr surf_lds;             // surface table in LDS; unused when !SURF_LDS
 
     __device__ __forceinline__ bool next(v3 & o_, v3 & d_, float & tmax)
     {
@@ -807,8 +817,9 @@ struct ShadowJob {
         const float e2 = dpp_f<0xED>(eA), e3 = dpp_f<0xED>(eB);     // quad_perm [1,3,2,3]: lane 0 <- 1, lane 1 <- 3
         if (c < 2) {
             if (visible) {
-                const float4 dc = surf_lds ? surf_lds[4 * surface + 2 + c]
-                                           : reinterpret_cast<const float4 *>(a.scene.surfaces + surface)[2 + c];   // diffuse
+                float4 dc;                                           // diffuse coefficients of this lane's four bands
+                if (SURF_LDS) dc = lds_load4(surf_lds, 4 * surface + 2 + c);
+                else dc = reinterpret_cast<const float4 *>(a.scene.surfaces + surface)[2 + c];
                 // kernel.cpp:480-485: newVol * attenuation * diffuse * DIFF, left to right
                 o.x = ((mine.x * e0) * dc.x) * diff;
                 o.y = ((mine.y * e1) * dc.y) * diff;
@@ -832,12 +843,16 @@ struct ShadowJob {
     }
 };
 
-__global__ __launch_bounds__(WAVE, 7) void shadow_kernel(TraceArgs a)
+#ifndef RVB_SHADOW_WAVES
+#define RVB_SHADOW_WAVES 8     // 64 VGPRs (8 waves/SIMD): 1.845 -> 1.807 ms against 7
+#endif
+template <bool SURF_LDS>
+__global__ __launch_bounds__(WAVE, RVB_SHADOW_WAVES) void shadow_kernel(TraceArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t stack_lds[];   // [stack_entries][QUADS_PER_BLOCK]
     const uint32_t c = threadIdx.x & 3u;
     const uint32_t q = threadIdx.x >> 2;
-    ShadowJob job = {a};
+    ShadowJob<SURF_LDS> job = {a};
     job.c = c;
     job.g = (uint64_t) blockIdx.x * QUADS_PER_BLOCK + q;
     job.stride = (uint64_t) gridDim.x * QUADS_PER_BLOCK;
@@ -894,7 +909,8 @@ void rvb_launch_path(const TraceArgs & a, hipStream_t s)
 {
     if (a.nrays == 0) return;
     const unsigned blocks = (unsigned) ((a.nrays + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK);
-    hipLaunchKernelGGL(path_kernel, dim3(blocks), dim3(WAVE), quad_kernel_lds_bytes(a), s, a);
+    if (a.lds_surfaces) hipLaunchKernelGGL(path_kernel<true>, dim3(blocks), dim3(WAVE), quad_kernel_lds_bytes(a), s, a);
+    else hipLaunchKernelGGL(path_kernel<false>, dim3(blocks), dim3(WAVE), quad_kernel_lds_bytes(a), s, a);
 }
 
 void rvb_launch_images(const TraceArgs & a, hipStream_t s)
@@ -911,5 +927,6 @@ void rvb_launch_shadow(const TraceArgs & a, hipStream_t s)
     uint64_t blocks = (total + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK;
     static const uint64_t per_cu = getenv("RVB_SHADOW_WG_PER_CU") ? strtoull(getenv("RVB_SHADOW_WG_PER_CU"), nullptr, 10) : 256;
     if (blocks > 256u * per_cu) blocks = 256u * per_cu;     // single-wave workgroups per CU; records beyond are grid-strided
-    hipLaunchKernelGGL(shadow_kernel, dim3((unsigned) blocks), dim3(WAVE), quad_kernel_lds_bytes(a), s, a);
+    if (a.lds_surfaces) hipLaunchKernelGGL(shadow_kernel<true>, dim3((unsigned) blocks), dim3(WAVE), quad_kernel_lds_bytes(a), s, a);
+    else hipLaunchKernelGGL(shadow_kernel<false>, dim3((unsigned) blocks), dim3(WAVE), quad_kernel_lds_bytes(a), s, a);
 }

@@ -67,6 +67,8 @@ struct Sim {
     Policy pol;
     // counters
     unsigned long long node_steps = 0, node_steps_allculled = 0, leaf_steps = 0, pop_culls = 0, pushes = 0;
+    unsigned long long by_level[32] = {0}, hits_by_level[32] = {0};
+    std::vector<uint8_t> level;          // depth of every node
 
     void begin(Query & q, v3 o, v3 d, bool any, float tmax)
     {
@@ -97,6 +99,8 @@ struct Sim {
     {
         ++node_steps;
         const BvhNode & n = bs.nodes[q.ref >> RVB_BVH_NODE_SHIFT];
+        const int lvl = level.empty() ? 0 : level[q.ref >> RVB_BVH_NODE_SHIFT];
+        ++by_level[lvl];
         const float lim = limit(q), neg_cull = -cull_abs;
         bool ok[4]; float tn[4];
         int nok = 0;
@@ -113,6 +117,7 @@ struct Sim {
             tn[c] = fmaxf(a, 0.0f);
             nok += ok[c];
         }
+        hits_by_level[lvl] += nok;
         if (!nok) { ++node_steps_allculled; pop(q); return; }
         int winner = -1;
         if (q.any) { for (int c = 0; c < 4; ++c) if (ok[c]) { winner = c; break; } }
@@ -164,7 +169,27 @@ int main(int argc, char ** argv)
     std::string err = rvb_build_scene((const rvb_triangle *) tb.data(), ntri, (const rvb_float3 *) vb.data(), nvert, 1000, base.bs);
     if (!err.empty()) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
     base.cull_abs = base.bs.pad; base.cull_rel = 1e-4f;
-    printf("nodes %zu tris %zu depth %u stack_need %u\n", base.bs.nodes.size(), base.bs.tris.size(), base.bs.depth, base.bs.stack_need);
+    base.level.assign(base.bs.nodes.size(), 0);
+    for (size_t i = 0; i < base.bs.nodes.size(); ++i)
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t r = base.bs.nodes[i].c[k].ref;
+            if (r != RVB_BVH_EMPTY && !(r & RVB_BVH_LEAF)) base.level[r >> RVB_BVH_NODE_SHIFT] = base.level[i] + 1;
+        }
+    {
+        size_t leaves = 0, hist[5] = {0, 0, 0, 0, 0}, kids[5] = {0, 0, 0, 0, 0};
+        for (const BvhNode & n : base.bs.nodes) {
+            int nk = 0;
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t r = n.c[k].ref;
+                if (r == RVB_BVH_EMPTY) continue;
+                ++nk;
+                if (r & RVB_BVH_LEAF) { ++leaves; ++hist[((r >> 28) & 7u) + 1]; }
+            }
+            ++kids[nk];
+        }
+        printf("nodes %zu tris %zu depth %u stack_need %u | leaves %zu with 1/2/3/4 tris: %zu %zu %zu %zu | nodes with 1/2/3/4 children: %zu %zu %zu %zu\n",
+               base.bs.nodes.size(), base.bs.tris.size(), base.bs.depth, base.bs.stack_need, leaves, hist[1], hist[2], hist[3], hist[4], kids[1], kids[2], kids[3], kids[4]);
+    }
     const float * dirs = (const float *) db.data();
 
     const double C_NODE = 57, C_LEAF = 160, C_DONE = 150;        // wave instructions per step (from the ISA)
@@ -247,6 +272,11 @@ int main(int argc, char ** argv)
                sched, T, (double) s.node_steps / bounces, (double) s.leaf_steps / bounces, wn, wl, wd,
                (double) q_node_active / w_node, (double) q_leaf_active / w_leaf, (double) q_done_active / w_done,
                wn * C_NODE + wl * C_LEAF + wd * C_DONE);
+        if (p == 0) {
+            printf("   node visits per bounce by tree level (children hit per visit):");
+            for (int l = 0; l < 12; ++l) if (s.by_level[l]) printf(" L%d %.2f (%.2f)", l, (double) s.by_level[l] / bounces, (double) s.hits_by_level[l] / s.by_level[l]);
+            printf("\n");
+        }
         if (p > 1) continue;
         // ---- shadow_kernel replay: records grouped by leaf position, 16 consecutive records per wave pass
         {
