@@ -28,6 +28,8 @@ rvb_import.load()
 from parallel_reverb_raytracer_amd import capi, distributed, dtypes, scenes  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 4   # 256 CUs x 4 SIMDs, one VALU wave-instruction per 4 cycles at 2.4 GHz = 614.4 G/s
+PMC_FILE = "r01b_pmc_n1.json"
 
 
 def parse():
@@ -173,19 +175,28 @@ def main():
         dominant = max(avg, key=avg.get)
         ach = algorithmic.get(dominant, 0.0) / (avg[dominant] * 1e-3) / 1e9
         # HBM traffic per launch from the committed PMC passes of this same command (profiles/), if the workload matches
-        traffic = {}
+        traffic, valu_insts = {}, {}
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_n1.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
             if (nrays, nrefl, args.triangles, world) == (100000, 128, 75000, 1):
-                traffic = {k: v["hbm_bytes_per_launch"] for k, v in pmc["kernels"].items()}
+                traffic = {k: v["hbm_bytes_per_launch"] for k, v in pmc["kernels"].items() if "hbm_bytes_per_launch" in v}
+                valu_insts = {k: v["SQ_INSTS_VALU"] for k, v in pmc["kernels"].items() if "SQ_INSTS_VALU" in v}
         except (OSError, ValueError, KeyError):
             pass
         roofline = {"kernel": dominant, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic.get(dominant),
-                    "traffic_source": "profiles/r01_pmc_traffic_n1.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)" if traffic else None,
+                    "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)" % PMC_FILE if traffic else None,
                     "avg_launch_ms": avg[dominant],
-                    "note": "trace kernels are latency/VALU-bound by construction (scene + BVH are cache-resident); "
+                    "note": "trace kernels are VALU-issue-bound by construction (scene + BVH are cache-resident): see roofline_valu; "
                             "the HBM-bound kernels of the path are reported in roofline_stream"}
+        # What actually bounds the trace kernels: VALU issue.  achieved = VALU wave-instructions per launch (PMC SQ_INSTS_VALU of
+        # this same command, a property of the workload) / live launch time; peak = 1024 SIMDs x one wave-instruction per 4 cycles.
+        valu = {}
+        for k in ("path_kernel", "shadow_kernel"):
+            if k in valu_insts and avg.get(k):
+                a = valu_insts[k] / (avg[k] * 1e-3) / 1e9
+                valu[k] = {"bound": "valu_issue", "achieved": a, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
+                           "frac": a / VALU_PEAK_GINST, "avg_launch_ms": avg[k], "valu_instructions_per_launch": valu_insts[k]}
         stream = {}
         for k in ("shadow_kernel", "time_range_kernel", "histogram_fast_kernel"):
             if k in avg and avg[k] > 0:
@@ -211,7 +222,7 @@ def main():
             "executed_bounces_rank0": int(executed), "nominal_bounces_rank0": nrays * nrefl,
             "kernel_ms": avg, "nbins": state["nbins"], "image_sources": state["images"], "predelay_s": state["predelay"],
             "scene_build_upload_ms": scene_ms, "bvh": ctx.scene_info(),
-            "roofline": roofline, "roofline_stream": stream,
+            "roofline": roofline, "roofline_stream": stream, "roofline_valu": valu,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene, mic, src, nrefl, args.cpu_seconds)

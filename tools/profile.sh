@@ -1,0 +1,24 @@
+#!/bin/bash
+# Profiles of the default bench command on the GPU box (run through gpurun): one kernel-trace + stats pass and separate
+# PMC passes (a pass never mixes --pmc with a trace domain other than --kernel-trace; FETCH_SIZE and WRITE_SIZE do not fit
+# in one pass — MI355X_MICROARCH.md "rocprofv3 PMC slots").  Raw output under gpurun_out/<tag>_*, summaries by
+# tools/profile_summary.py.        tools/profile.sh <tag>
+set -u
+tag=$1
+cd "${GRAFT_REPO_ROOT:-$PWD}"
+root=$PWD
+export TMPDIR=/tmp
+out=$root/gpurun_out
+mkdir -p "$out"
+BENCH="python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats" -o run -- $BENCH > "$out/${tag}_bench_under_rocprof.json" 2> "$out/${tag}_stats.err" || echo "stats pass failed"
+for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_ATOMIC_sum" \
+           "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU" \
+           "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAVES GRBM_GUI_ACTIVE"; do
+    name=$(echo "$set" | cut -d' ' -f1)
+    rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$out/${tag}_pmc_$name" -o run -- $BENCH > /dev/null 2> "$out/${tag}_pmc_$name.err" || echo "pmc pass $name failed"
+    echo "pass $name done"
+done
+cd "$root"
+python3 tools/profile_summary.py "$tag"

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Summarises the raw rocprofv3 output of tools/profile.sh <tag> (gpurun_out/<tag>_*) into
+gpurun_out/<tag>_kernel_stats.csv (our kernels + the sort) and gpurun_out/<tag>_pmc.json (per-launch averages of every
+counter per kernel, HBM bytes with the gfx950 FETCH_SIZE correction, VALU issue share)."""
+import csv
+import glob
+import json
+import os
+import sys
+
+tag = sys.argv[1]
+out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+SHORT = ["path_kernel", "image_kernel", "shadow_kernel", "histogram_fast_kernel", "histogram_transpose_kernel", "attenuate_kernel",
+         "time_range_kernel", "radix_sort_onesweep_iteration", "radix_sort_onesweep_global_offsets"]
+
+
+def short(name):
+    for s in SHORT:
+        if s in name:
+            return s
+    return None
+
+
+# kernel stats: keep the full csv, print ours
+stats = glob.glob(os.path.join(out, tag + "_stats", "**", "*kernel_stats.csv"), recursive=True)
+if stats:
+    rows = list(csv.DictReader(open(stats[0])))
+    with open(os.path.join(out, tag + "_kernel_stats.csv"), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        for r in rows:
+            s = short(r["Name"])
+            w.writerow([s or r["Name"][:80], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+            if s:
+                print("%-36s calls %3s avg %10.1f us" % (s, r["Calls"], float(r["AverageNs"]) / 1e3))
+
+pmc = {}
+for d in sorted(glob.glob(os.path.join(out, tag + "_pmc_*"))):
+    if not os.path.isdir(d):
+        continue
+    for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        acc = {}
+        for r in csv.DictReader(open(path)):
+            s = short(r["Kernel_Name"])
+            if not s:
+                continue
+            key = (s, r["Counter_Name"])
+            a = acc.setdefault(key, [0.0, set()])
+            a[0] += float(r["Counter_Value"])
+            a[1].add(r["Dispatch_Id"])
+        for (s, c), (total, disp) in acc.items():
+            pmc.setdefault(s, {})[c] = total / max(1, len(disp))
+for s, c in pmc.items():
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        c["hbm_bytes_per_launch"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+    if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c and c["TCC_HIT_sum"] + c["TCC_MISS_sum"] > 0:
+        c["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+    if "SQ_ACTIVE_INST_VALU" in c and "SQ_BUSY_CYCLES" in c and c["SQ_BUSY_CYCLES"] > 0:
+        # SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES count quad-cycles (MI355X_MICROARCH.md "s_memtime tick vs SQ PMC units")
+        c["valu_active_share_of_wave_cycles"] = c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else None
+        c["wait_any_share_of_wave_cycles"] = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") and "SQ_WAIT_ANY" in c else None
+json.dump({"_how": "tools/profile.sh %s: rocprofv3 --kernel-trace --pmc <one set per pass> -- python3 bench.py --steps 3 --warmup 1 "
+                   "--no-cpu-baseline; per-launch averages; hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 FETCH_SIZE counts "
+                   "128-B requests as 64 B: MI355X_MICROARCH.md HBM section; upper bound for gather-heavy kernels)" % tag,
+           "kernels": pmc}, open(os.path.join(out, tag + "_pmc.json"), "w"), indent=1)
+print(json.dumps({k: {c: round(v, 4) if isinstance(v, float) else v for c, v in d.items() if not c.startswith("SQ_INSTS_V")} for k, d in pmc.items()
+                  if k in ("path_kernel", "shadow_kernel")}, indent=1))
