@@ -64,6 +64,9 @@ int rvb_create(rvb_ctx ** out, int device, unsigned flags);
 void rvb_destroy(rvb_ctx * ctx);
 const char * rvb_last_error(const rvb_ctx * ctx);       /* ctx may be NULL after a failed rvb_create */
 int rvb_synchronize(rvb_ctx * ctx);                     /* wait for the context's stream */
+/* Work submitted to the context after this call starts only after `hip_event` (a hipEvent_t recorded on another stream,
+ * e.g. the one a caller-owned buffer was zeroed on) has completed.  No host synchronisation. */
+int rvb_wait_for_event(rvb_ctx * ctx, void * hip_event);
 /* Name ("gfx950"), compute-unit count and HBM bytes of the bound device. */
 int rvb_device_info(rvb_ctx * ctx, char * arch, uint64_t arch_capacity, int * compute_units, uint64_t * hbm_bytes);
 

@@ -23,7 +23,7 @@ IR_FAST, IR_EXACT = 0, 1
 
 # every symbol include/rvb_capi.h declares
 SYMBOLS = [
-    "rvb_create", "rvb_destroy", "rvb_last_error", "rvb_synchronize", "rvb_device_info",
+    "rvb_create", "rvb_destroy", "rvb_last_error", "rvb_synchronize", "rvb_wait_for_event", "rvb_device_info",
     "rvb_set_scene", "rvb_scene_info", "rvb_set_directions", "rvb_set_directions_device", "rvb_trace",
     "rvb_get_diffuse", "rvb_diffuse_device", "rvb_get_direct", "rvb_get_image_candidates", "rvb_merge_images",
     "rvb_attenuate_speaker", "rvb_attenuate_speaker_device", "rvb_attenuate_hrtf", "rvb_flatten",
@@ -275,9 +275,15 @@ class Context:
                                                ctypes.c_int(mode), _vp(device_histogram_pointer)))
 
     def ir_accumulate_tensor(self, predelay, sample_rate, nbins, mode, tensor):
-        """Adds into a zeroed torch CUDA tensor [nchannels][8][nbins] (plumbing for distributed.py)."""
+        """Adds into a zeroed torch CUDA tensor [nchannels][8][nbins] (plumbing for distributed.py).  The tensor was
+        filled on torch's current stream: the context's stream waits for that fill through an event, the host does not."""
+        import torch
         assert tensor.is_cuda and tensor.is_contiguous() and tensor.numel() == self.nchannels * 8 * nbins
+        ready = torch.cuda.Event()
+        ready.record()
+        self._check(self.lib.rvb_wait_for_event(self.handle, _vp(ready.cuda_event)))
         self.ir_accumulate(predelay, sample_rate, nbins, mode, tensor.data_ptr())
+        self._keep_event = ready                       # alive until the next call (the wait has been enqueued, not executed)
 
     def ir_download(self, trim_predelay, sample_rate, mode=IR_FAST):
         """attenuate -> fixPredelay -> flattenImpulses (reference cmd/main.cpp:280-298) -> [nch][8][nbins]."""

@@ -65,6 +65,7 @@ struct rvb_ctx {
     float mic[3] = {0, 0, 0};
     DevBuf impulses, early, candidates, small, stamps, sort_keys, sort_scratch, sort_order, group_temp;       // small: [0] candidate count, [2..3] executed, [16..] direct, range
     unsigned char small_host[128] = {0};        // host mirror of `small`, fetched once per trace
+    rvb_image_candidate first_candidates[32];   // ... together with the first few image-source candidates (usually all of them)
     bool small_valid = false;
     std::vector<Timing> timings;
     std::vector<hipEvent_t> event_pool;
@@ -169,8 +170,12 @@ int rvb_create(rvb_ctx ** out, int device, unsigned flags)
     ctx->arch = prop.gcnArchName;
     ctx->compute_units = prop.multiProcessorCount;
     ctx->hbm_bytes = prop.totalGlobalMem;
-    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking)) != hipSuccess ||
+    // The side stream (image_kernel) runs at the lowest priority: the record grouping on the main stream is the critical
+    // path between path_kernel and shadow_kernel and must not queue behind image_kernel's 14 k workgroups.
+    int prio_least = 0, prio_greatest = 0;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest)) != hipSuccess ||
+        (e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_greatest)) != hipSuccess ||
+        (e = hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, prio_least)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->path_done, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->side_done, hipEventDisableTiming)) != hipSuccess ||
         (e = ctx->small.ensure(kSmallBytes)) != hipSuccess) {
@@ -203,6 +208,14 @@ void rvb_destroy(rvb_ctx * ctx)
 const char * rvb_last_error(const rvb_ctx * ctx)
 {
     return ctx ? ctx->error.c_str() : g_create_error.c_str();
+}
+
+int rvb_wait_for_event(rvb_ctx * ctx, void * hip_event)
+{
+    if (!ctx || !hip_event) return RVB_ERR_INVALID;
+    RVB_BIND(ctx);
+    RVB_HIP(ctx, hipStreamWaitEvent(ctx->stream, reinterpret_cast<hipEvent_t>(hip_event), 0));
+    return RVB_OK;
 }
 
 int rvb_synchronize(rvb_ctx * ctx)
@@ -412,6 +425,10 @@ static int fetch_small(rvb_ctx * ctx)
     if (ctx->small_valid)
         return RVB_OK;
     RVB_HIP(ctx, hipMemcpyAsync(ctx->small_host, ctx->small.p, kSmallBytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->nrays)      // capacity nrays * 9 >= 32 entries unless there are fewer than 4 rays
+        RVB_HIP(ctx, hipMemcpyAsync(ctx->first_candidates, ctx->candidates.p,
+                                    std::min(sizeof(ctx->first_candidates), (size_t) ctx->nrays * 9 * sizeof(rvb_image_candidate)),
+                                    hipMemcpyDeviceToHost, ctx->stream));
     RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->small_valid = true;
     return RVB_OK;
@@ -466,7 +483,10 @@ int rvb_get_image_candidates(rvb_ctx * ctx, rvb_image_candidate * out, uint64_t 
     if (capacity < n)
         return fail(ctx, RVB_ERR_CAPACITY, "rvb_get_image_candidates: capacity too small");
     if (n) {
-        RVB_HIP(ctx, hipMemcpy(out, ctx->candidates.p, (size_t) n * sizeof(rvb_image_candidate), hipMemcpyDeviceToHost));
+        if (n <= sizeof(ctx->first_candidates) / sizeof(rvb_image_candidate))
+            std::memcpy(out, ctx->first_candidates, (size_t) n * sizeof(rvb_image_candidate));     // came with the small block
+        else
+            RVB_HIP(ctx, hipMemcpy(out, ctx->candidates.p, (size_t) n * sizeof(rvb_image_candidate), hipMemcpyDeviceToHost));
         std::sort(out, out + n, [](const rvb_image_candidate & x, const rvb_image_candidate & y) {
             return x.ray != y.ray ? x.ray < y.ray : x.slot < y.slot;
         });
@@ -663,11 +683,14 @@ static int configure_common(rvb_ctx * ctx, int which, const rvb_impulse * images
     if (!ctx->traced) return fail(ctx, RVB_ERR_STATE, "rvb_ir_configure: nothing traced");
     if (which < 1 || which > 3) return fail(ctx, RVB_ERR_INVALID, "rvb_ir_configure: which must be 1..3");
     if (nimages && !images) return fail(ctx, RVB_ERR_INVALID, "rvb_ir_configure: null images");
-    RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (nimages * sizeof(rvb_impulse) > ctx->images.cap)
+        RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));          // the buffer is about to be replaced
     RVB_HIP(ctx, ctx->images.ensure(nimages * sizeof(rvb_impulse)));
-    if (nimages) RVB_HIP(ctx, hipMemcpy(ctx->images.p, images, nimages * sizeof(rvb_impulse), hipMemcpyHostToDevice));
     ctx->nimages = nimages;
     ctx->images_host.assign(images, images + nimages);
+    // in stream order (kernels of an earlier configuration that read the old images run before it); the source is the
+    // context's own copy, which lives until the next configure
+    if (nimages) RVB_HIP(ctx, hipMemcpyAsync(ctx->images.p, ctx->images_host.data(), nimages * sizeof(rvb_impulse), hipMemcpyHostToDevice, ctx->stream));
     ctx->which = which;
     ctx->ir_configured = true;
     return RVB_OK;

@@ -245,9 +245,12 @@ __global__ __launch_bounds__(256) void time_range_kernel(ModelDev m, const float
         tmin = fminf(tmin, __shfl_xor(tmin, off));
         tmax = fmaxf(tmax, __shfl_xor(tmax, off));
     }
+    // One atomic per wave only when it can still move the result: with one workgroup per 4 KiB there are millions of waves,
+    // and that many atomics on two addresses serialise (70 ms at 12.8 M impulses).  A stale read only costs a redundant atomic.
     if ((threadIdx.x & 63u) == 0) {
-        if (tmin != __builtin_inff()) atomicMin(range + 0, __float_as_uint(tmin));
-        atomicMax(range + 1, __float_as_uint(tmax));
+        const volatile uint32_t * seen = range;
+        if (tmin != __builtin_inff() && __float_as_uint(tmin) < seen[0]) atomicMin(range + 0, __float_as_uint(tmin));
+        if (__float_as_uint(tmax) > seen[1]) atomicMax(range + 1, __float_as_uint(tmax));
     }
 }
 
@@ -440,8 +443,8 @@ __global__ __launch_bounds__(256) void flat_keys_kernel(const rvb_attenuated_imp
     }
     for (int off = 32; off > 0; off >>= 1)
         tmax = fmaxf(tmax, __shfl_xor(tmax, off));
-    if ((threadIdx.x & 63u) == 0)
-        atomicMax(max_time_bits, __float_as_uint(tmax));
+    if ((threadIdx.x & 63u) == 0 && __float_as_uint(tmax) > *(const volatile uint32_t *) max_time_bits)
+        atomicMax(max_time_bits, __float_as_uint(tmax));     // only a wave that can still raise the maximum pays for the atomic
 }
 
 __global__ __launch_bounds__(64) void flat_ordered_sum_kernel(const rvb_attenuated_impulse * __restrict__ in,

@@ -881,8 +881,9 @@ __global__ __launch_bounds__(WAVE, RVB_SHADOW_WAVES) void shadow_kernel(TraceArg
         tmax_seen = fmaxf(tmax_seen, __shfl_xor(tmax_seen, off));
     }
     if (threadIdx.x == 0) {                       // non-negative floats order like their bit patterns
-        if (tmin != __builtin_inff()) atomicMin(a.time_range + 0, __float_as_uint(tmin));
-        atomicMax(a.time_range + 1, __float_as_uint(tmax_seen));
+        const volatile uint32_t * seen = a.time_range;    // skip the atomic when it cannot move the result (stale reads are harmless)
+        if (tmin != __builtin_inff() && __float_as_uint(tmin) < seen[0]) atomicMin(a.time_range + 0, __float_as_uint(tmin));
+        if (__float_as_uint(tmax_seen) > seen[1]) atomicMax(a.time_range + 1, __float_as_uint(tmax_seen));
     }
 }
 

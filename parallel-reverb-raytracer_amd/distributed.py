@@ -129,9 +129,7 @@ def generate_ir(tracer, mic, source, nreflections, air, speakers_dir, speakers_c
     predelay = lo if trim_predelay else 0.0
     nbins = tracer.ir_bins(hi, predelay, sample_rate)
     hist = torch.zeros((len(speakers_coeff), 8, nbins), device=device, dtype=torch.float32)
-    if hist.is_cuda:
-        torch.cuda.synchronize()                         # the zero fill ran on torch's stream
-    if contributes:
+    if contributes:                                      # (the tracer's stream waits for torch's zero fill by an event)
         tracer.ir_accumulate_tensor(predelay, sample_rate, nbins, mode, hist)
     if on_stage:
         on_stage("accumulate")

@@ -101,6 +101,33 @@ def test_trace_matches_oracle_on_seeded_scenes(ctx, oracle, name, make, nrays, n
     assert ctx.executed_bounces() >= executed
 
 
+def grazing_directions(n, seed, max_slope):
+    """Unit vectors within `max_slope` of the horizontal plane, random azimuth: rays that skim the floor and ceiling of a room
+    and meet their triangles nearly edge-on, where |det| sits just above the reference's 1e-4 rejection threshold and the float
+    Möller–Trumbore result is least accurate (kernel.cpp:62-88)."""
+    rng = np.random.default_rng(seed)
+    az = rng.uniform(-np.pi, np.pi, n)
+    slope = rng.uniform(-max_slope, max_slope, n)
+    d = np.stack([np.cos(az), slope, np.sin(az)], -1)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    from parallel_reverb_raytracer_amd.dtypes import float3_array
+    return float3_array(d.astype(np.float32))
+
+
+@pytest.mark.parametrize("height,slope", [(0.002, 0.003), (0.02, 0.0005), (0.2, 0.02), (2.0, 0.003)])
+def test_grazing_rays_match_brute_force(ctx, oracle, height, slope):
+    """The BVH may only prune what the brute-force scan would reject: stress the padded boxes and the cull slack with
+    rays launched millimetres above a finely tessellated floor at grazing angles (bit-exact against the oracle)."""
+    scene = scenes.rotated_square_room(n=16)                       # 3072 triangles, 38 m x 27 m
+    mic, src = (-3.0, 4.0, 2.0), (0.5, height, 0.25)
+    dirs = grazing_directions(4096, seed=int(height * 1000) + 1, max_slope=slope)
+    ctx.set_scene(scene)
+    ctx.raytrace(mic, src, dirs, 16, AIR_COEFFICIENTS)
+    want, image, index = oracle.raytrace(scene, mic, src, dirs, 16, AIR_COEFFICIENTS)
+    assert_impulses_equal(ctx.get_raw_diffuse(), want, "grazing h=%g slope=%g" % (height, slope))
+    assert_impulses_equal(ctx.get_raw_images(False), oracle.collect_images(image, index, False), "grazing images")
+
+
 def test_edge_cases_empty_and_ragged(ctx, oracle):
     scene = scenes.rotated_square_room(n=1)
     ctx.set_scene(scene)

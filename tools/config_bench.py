@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Developer tool: per-kernel timings of the BASELINE.json configurations other than the bench line's (C3 per-GPU share,
+C4, C5) on one GPU — the numbers DESIGN.md quotes for them.  Same code path as bench.py (fused IR, fast histogram).
+    python tools/config_bench.py > gpurun_out/config_bench.json"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import rvb_import  # noqa: E402
+
+rvb_import.load()
+import torch  # noqa: E402
+from parallel_reverb_raytracer_amd import capi, dtypes, scenes  # noqa: E402
+
+
+def run(name, scene, mic, src, nrays, nrefl, model, steps=4):
+    ctx = capi.Context(0)
+    t0 = time.perf_counter()
+    ctx.set_scene(scene)
+    build_ms = (time.perf_counter() - t0) * 1e3
+    dirs = torch.from_numpy(np.ascontiguousarray(scenes.sphere_directions(nrays, seed=1))).cuda()
+    torch.cuda.synchronize()
+    ctx.set_directions_device(dirs.data_ptr(), nrays)
+    table = scenes.hrtf_synthetic_table() if model == "hrtf" else None
+    facing = np.asarray(src, np.float32) - np.asarray(mic, np.float32)
+    facing = facing / np.linalg.norm(facing)
+    kernels, wall = {}, []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        ctx.trace(mic, src, nrefl, dtypes.AIR_COEFFICIENTS)
+        cands, direct = ctx.get_image_candidates(), ctx.get_direct()
+        trace_t = dict(ctx.last_timings())
+        images = capi.merge_images(cands, direct, False)
+        if model == "hrtf":
+            ctx.ir_configure_hrtf(mic, table, facing, (0, 1, 0), capi.IR_ALL, images)
+        else:
+            ctx.ir_configure_speakers(mic, [(-1, 0, -1), (1, 0, -1)], [0.5, 0.5], capi.IR_ALL, images)
+        lo, hi = ctx.ir_time_range()
+        range_t = dict(ctx.last_timings())
+        nbins = ctx.ir_bins(hi, lo, 44100.0)
+        hist = torch.zeros((2, 8, nbins), device="cuda", dtype=torch.float32)
+        ctx.ir_accumulate_tensor(lo, 44100.0, nbins, capi.IR_FAST, hist)
+        ctx.synchronize()
+        acc_t = dict(ctx.last_timings())
+        if it:                                   # first iteration allocates
+            wall.append((time.perf_counter() - t0) * 1e3)
+            for d in (trace_t, range_t, acc_t):
+                for k, v in d.items():
+                    kernels.setdefault(k, []).append(v)
+    ms = float(np.mean(wall))
+    out = {"config": name, "triangles": int(scene[0].shape[0]), "rays": nrays, "reflections": nrefl, "model": model,
+           "ms_per_ir": ms, "ray_bounces_per_sec": nrays * nrefl / (ms * 1e-3), "executed_bounces": int(ctx.executed_bounces()),
+           "kernel_ms": {k: float(np.mean(v)) for k, v in kernels.items()}, "nbins": int(nbins), "images": int(images.shape[0]),
+           "scene_build_upload_ms": build_ms, "bvh": ctx.scene_info()}
+    ctx.close()
+    return out
+
+
+def main():
+    results = []
+    scene, info = scenes.cathedral(75000)
+    results.append(run("C3 per-GPU share: cathedral stand-in, 125k rays x 128", scene, info["mic"], info["source"], 125000, 128, "speakers"))
+    scene, info = scenes.atrium(262000)
+    results.append(run("C4: atrium stand-in, 100k rays x 256", scene, info["mic"], info["source"], 100000, 256, "speakers"))
+    scene, _ = scenes.concert_hall(30000)
+    src, mic = scenes.source_mic_pairs(64, seed=0)
+    results.append(run("C5 one of 64 pairs: concert-hall stand-in, 100k rays x 128, HRTF", scene, mic[0], src[0], 100000, 128, "hrtf"))
+    print(json.dumps(results, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -37,7 +37,8 @@ static float half_to_float(uint16_t b)
 struct Policy {
     bool stack_dist = false;     // stack entries carry the entry distance; culled at pop time without a node visit
     bool sorted_push = false;    // siblings pushed far-to-near (nearest popped first) instead of lane order
-    int postpone = 0;            // leaves a quad may hold back while it keeps walking nodes (Aila-Laine speculative traversal)
+    int postpone = 0;
+    int any_order = 0;           // any-hit child order: 0 first hit lane (shipped), 1 nearest first, 2 farthest first            // leaves a quad may hold back while it keeps walking nodes (Aila-Laine speculative traversal)
 };
 
 struct Query {
@@ -120,7 +121,8 @@ struct Sim {
         hits_by_level[lvl] += nok;
         if (!nok) { ++node_steps_allculled; pop(q); return; }
         int winner = -1;
-        if (q.any) { for (int c = 0; c < 4; ++c) if (ok[c]) { winner = c; break; } }
+        if (q.any && pol.any_order == 0) { for (int c = 0; c < 4; ++c) if (ok[c]) { winner = c; break; } }
+        else if (q.any) { for (int c = 0; c < 4; ++c) if (ok[c] && (winner < 0 || (pol.any_order == 1 ? tn[c] < tn[winner] : tn[c] > tn[winner]))) winner = c; }
         else {
             uint32_t bestk = 0xFFFFFFFFu;
             for (int c = 0; c < 4; ++c) if (ok[c]) {
@@ -191,9 +193,25 @@ int main(int argc, char ** argv)
                base.bs.nodes.size(), base.bs.tris.size(), base.bs.depth, base.bs.stack_need, leaves, hist[1], hist[2], hist[3], hist[4], kids[1], kids[2], kids[3], kids[4]);
     }
     const float * dirs = (const float *) db.data();
+    const bool verify = getenv("TRAVSIM_VERIFY") != nullptr;
+    const double grazing = getenv("TRAVSIM_GRAZING") ? atof(getenv("TRAVSIM_GRAZING")) : 0.0;
+    std::vector<float> gdirs;
+    if (grazing > 0.0) {                              // keep azimuth, squash the elevation: |d.y| in (0, grazing]
+        gdirs.assign(dirs, dirs + 4 * nrays);
+        for (uint64_t i = 0; i < nrays; ++i) {
+            double x = gdirs[4 * i], y = gdirs[4 * i + 1], z = gdirs[4 * i + 2];
+            double h = std::sqrt(x * x + z * z);
+            if (h == 0) { x = 1; h = 1; }
+            double e = grazing * (0.001 + 0.999 * std::fabs(y)) * (y < 0 ? -1 : 1);
+            double n = std::sqrt(1 + e * e);
+            gdirs[4 * i] = (float) (x / h / n); gdirs[4 * i + 1] = (float) (e / n); gdirs[4 * i + 2] = (float) (z / h / n);
+        }
+        dirs = gdirs.data();
+    }
+    unsigned long long verified = 0, mismatches = 0;
 
     const double C_NODE = 57, C_LEAF = 160, C_DONE = 150;        // wave instructions per step (from the ISA)
-    for (int p = 0; p < 14; ++p) {
+    for (int p = 0; p < (verify ? 1 : 14); ++p) {
         Sim s = base;
         s.pol.stack_dist = 0; s.pol.sorted_push = 0; s.pol.postpone = 0;
         // scheduler: 0 = while-while (shipped); 1 = majority vote; 2..: node loop runs while >= T quads want a node step
@@ -252,6 +270,19 @@ int main(int argc, char ** argv)
                 } else {
                     ++w_done; q_done_active += cd;
                     for (int i = 0; i < nq; ++i) if (st[i] == DONE) {
+                        if (verify && p == 0) {
+                            float bt = 0; uint32_t bi = 0xFFFFFFFFu;
+                            for (const BvhTri & t : s.bs.tris) {
+                                float dist = mt_intersect(mk3(t.v0[0], t.v0[1], t.v0[2]), mk3(t.e0[0], t.e0[1], t.e0[2]), mk3(t.e1[0], t.e1[1], t.e1[2]), q[i].o, q[i].d);
+                                if (dist > RVB_EPSILON && (bi == 0xFFFFFFFFu || dist < bt || (dist == bt && t.index < bi))) { bt = dist; bi = t.index; }
+                            }
+                            ++verified;
+                            if (bi != q[i].best_i || (bi != 0xFFFFFFFFu && bt != q[i].best_t)) {
+                                if (++mismatches <= 10)
+                                    printf("MISMATCH ray %llu bounce %u: bvh tri %u t %.9g, brute tri %u t %.9g  o=(%.9g %.9g %.9g) d=(%.9g %.9g %.9g)\n",
+                                           (unsigned long long) (w + i), r[i].bounce, q[i].best_i, q[i].best_t, bi, bt, q[i].o.x, q[i].o.y, q[i].o.z, q[i].d.x, q[i].d.y, q[i].d.z);
+                            }
+                        }
                         if (q[i].best_i == 0xFFFFFFFFu) { st[i] = IDLE; continue; }
                         ++bounces;
                         const TriShade & sh = s.bs.shade[q[i].best_i];
@@ -284,17 +315,17 @@ int main(int argc, char ** argv)
             for (size_t i = 0; i < order.size(); ++i) order[i] = (uint32_t) i;
             std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return base.bs.leafpos[hittri[a]] < base.bs.leafpos[hittri[b]]; });
             const double CS_NODE = 40, CS_LEAF = 100, CS_DONE = 150;
-            for (int mode = 0; mode < 3; ++mode) {       // 0 lockstep passes (shipped), 1 job loop while-while, 2 job loop majority vote
-                Sim sh = base;
+            for (int mode = 0; mode < 3; ++mode) {       // 0 lockstep passes (shipped); here: any-hit child order 0/1/2
+                Sim sh = base; sh.pol.any_order = mode;
                 unsigned long long w_node = 0, w_leaf = 0, w_done = 0, an = 0, al = 0, ad = 0;
                 const size_t J = 32;                      // records per quad in the job-loop modes
-                const size_t per_wave = mode == 0 ? 16 : 16 * J;
+                const size_t per_wave = 16; (void) J;
                 for (size_t w0 = 0; w0 + per_wave <= order.size(); w0 += per_wave) {
                     Query q[16];
                     enum { NODE, LEAF, DONE, IDLE } st[16];
                     size_t nextj[16];
                     auto start = [&](int i) {
-                        if (nextj[i] >= (mode == 0 ? 1 : J)) { st[i] = IDLE; return; }
+                        if (nextj[i] >= 1) { st[i] = IDLE; return; }
                         const v3 pnt = hitpts[order[w0 + nextj[i] * 16 + i]];
                         ++nextj[i];
                         v3 b2p = mic - pnt;
@@ -312,7 +343,7 @@ int main(int argc, char ** argv)
                         for (int i = 0; i < 16; ++i) { cn += st[i] == NODE; cl += st[i] == LEAF; cd += st[i] == DONE; }
                         if (cn + cl + cd == 0) break;
                         int act;
-                        if (mode == 0) {
+                        if (true) {
                             // traverse_quad per record: node while any, leaf, repeat until all finished; then one done for all
                             if (cn) act = NODE; else if (cl) act = LEAF; else act = DONE;
                         } else if (mode == 1) {
@@ -337,5 +368,6 @@ int main(int argc, char ** argv)
             }
         }
     }
+    if (verify) printf("verify: %llu closest-hit queries against brute force, %llu mismatches\n", verified, mismatches);
     return 0;
 }
