@@ -223,6 +223,9 @@ std::string rvb_build_scene(const rvb_triangle * triangles, uint64_t ntriangles,
             }
         }
     for (int a = 0; a < 3; ++a) { out.bounds_lo[a] = scene.lo[a]; out.bounds_hi[a] = scene.hi[a]; }
+    // keeps every Möller–Trumbore determinant below 2^64, the range reciprocal_cr (rvb_math.h) is verified on
+    if (maxabs > 0x1p30f)
+        return "vertex coordinates beyond 2^30 are not supported";
     // Box padding: the float Möller–Trumbore test accepts hits a little outside the exact
     // triangle; 1 mm + 2e-5 of the coordinate range covers that with a wide margin.
     const float pad = std::max(1e-3f, 2e-5f * maxabs);

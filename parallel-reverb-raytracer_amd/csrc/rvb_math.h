@@ -48,6 +48,21 @@ RVB_HD float seconds_per_meter() { return (float) (1.0 / 340.000000); }
 // kernel.cpp:65-66 (e0 = v1 - v0, e1 = v2 - v0), precomputed with the same subtraction.
 struct TriEdges { v3 v0, e0, e1; };
 
+// 1.0f / x, correctly rounded.  On the device: v_rcp_f32 (1 ulp) + one FMA Newton step — three instructions instead of the
+// ten of the general division sequence.  tools/rcp_probe.hip compares it with `1.0f / x` for EVERY float with
+// 2^-17 <= |x| <= 2^64, both signs (1 358 954 498 values): no difference on gfx950.  mt_intersect only divides by
+// determinants with |det| >= EPSILON = 1e-4 > 2^-17, and rvb_build_scene rejects coordinates beyond 2^30, so |det| < 2^64.
+RVB_HD float reciprocal_cr(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r0 = __builtin_amdgcn_rcpf(x);
+    const float e0 = fmaf(-x, r0, 1.0f);
+    return fmaf(e0, r0, r0);
+#else
+    return 1.0f / x;
+#endif
+}
+
 // reference kernel.cpp:62-88 (triangle_vert_intersection).  Returns 0 for "no hit".
 RVB_HD float mt_intersect(const v3 & v0, const v3 & e0, const v3 & e1, const v3 & pos, const v3 & dir)
 {
@@ -55,7 +70,7 @@ RVB_HD float mt_intersect(const v3 & v0, const v3 & e0, const v3 & e1, const v3 
     float det = dot3(e0, pvec);
     if (-RVB_EPSILON < det && det < RVB_EPSILON)
         return 0.0f;
-    float invdet = 1.0f / det;
+    float invdet = reciprocal_cr(det);
     v3 tvec = pos - v0;
     float ucomp = invdet * dot3(tvec, pvec);
     if (ucomp < 0.0f || 1.0f < ucomp)

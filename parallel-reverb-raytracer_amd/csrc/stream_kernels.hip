@@ -203,40 +203,29 @@ __global__ __launch_bounds__(256) void attenuate_kernel(ModelDev m, uint32_t ch,
     }
 }
 
-// ---- 16 lanes per impulse: lane f of a group holds float f of the record ----------------------
-//   f 0..7 volume, 8..10 position, 12 time
-struct Group16 {
-    float mine;       // this lane's float
-    v3 pos;
-    float time;
-    bool nonzero;
-};
-
-__device__ __forceinline__ Group16 load_group16(const float * __restrict__ in, uint64_t word, uint64_t nwords)
+// min non-zero / max attenuated time (the inputs of findPredelay, rayverb.h:49-74, and of MAX_SAMPLE, rayverb.cpp:57).
+// Four lanes per impulse like attenuate_kernel: one 16-byte chunk per lane (1 KiB per wave instruction), position and
+// time broadcast by DPP, so the per-ear time shift (two square roots per ear) is evaluated once per 16 impulses and wave
+// instruction — the former 16-lanes-per-impulse layout spent four times the instructions on it and ran at 0.9 TB/s.
+__global__ __launch_bounds__(256) void time_range_kernel(ModelDev m, const float4 * __restrict__ in, uint64_t n, uint32_t * range)
 {
-    Group16 g;
-    const uint32_t lane = threadIdx.x & 63u;
-    const int base = (int) (lane & ~15u);
-    g.mine = word < nwords ? in[word] : 0.0f;
-    g.pos = mk3(__shfl(g.mine, base + 8), __shfl(g.mine, base + 9), __shfl(g.mine, base + 10));
-    g.time = __shfl(g.mine, base + 12);
-    const unsigned long long mask = __ballot((lane & 15u) < 8u && g.mine != 0.0f);
-    g.nonzero = ((mask >> base) & 0xFFull) != 0;
-    return g;
-}
-
-__global__ __launch_bounds__(256) void time_range_kernel(ModelDev m, const float * __restrict__ in, uint64_t n, uint32_t * range)
-{
-    const uint64_t nwords = n * 16;
+    const uint32_t q = threadIdx.x & 3u;
+    const uint64_t nchunks = n * 4;
     float tmin = __builtin_inff(), tmax = 0.0f;
-    for (uint64_t w = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; w < ((nwords + 63) & ~63ull);
-         w += (uint64_t) gridDim.x * blockDim.x) {
-        const Group16 g = load_group16(in, w, nwords);
-        if (!g.nonzero)
+    for (uint64_t c = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; c < nchunks; c += (uint64_t) gridDim.x * blockDim.x) {
+        const nt_float4_t t4 = __builtin_nontemporal_load(reinterpret_cast<const nt_float4_t *>(in + c));
+        const float4 v = make_float4(t4.x, t4.y, t4.z, t4.w);
+        const float px = qdpp_f<QUAD_BCAST(2)>(v.x), py = qdpp_f<QUAD_BCAST(2)>(v.y), pz = qdpp_f<QUAD_BCAST(2)>(v.z);
+        const float time = qdpp_f<QUAD_BCAST(3)>(v.x);
+        uint32_t nz = (q < 2 && (v.x != 0.0f || v.y != 0.0f || v.z != 0.0f || v.w != 0.0f)) ? 1u : 0u;
+        nz |= qdpp_u<QUAD_SWAP1>(nz);
+        nz |= qdpp_u<QUAD_SWAP2>(nz);
+        if (!nz)
             continue;           // attenuated impulse is {0, 0}: no part in findPredelay / maxtime
+        const v3 pos = mk3(px, py, pz);
         const uint32_t nch = m.hrtf ? 2u : 1u;   // speaker channels all keep the input time
         for (uint32_t ch = 0; ch < nch; ++ch) {
-            const float t = attenuated_time(m, ch, g.pos, g.time);
+            const float t = attenuated_time(m, ch, pos, time);
             if (t != 0.0f) tmin = fminf(tmin, t);
             tmax = fmaxf(tmax, t);
         }
@@ -496,8 +485,8 @@ void rvb_launch_attenuate(const AttenuationModel & m, uint32_t channel, const rv
 void rvb_launch_time_range(const AttenuationModel & m, const rvb_impulse * in, uint64_t n, uint32_t * range, hipStream_t s)
 {
     if (n == 0) return;
-    hipLaunchKernelGGL(time_range_kernel, dim3(stream_blocks(n * 16, 256)), dim3(256), 0, s, make_model(m),
-                       reinterpret_cast<const float *>(in), n, range);
+    hipLaunchKernelGGL(time_range_kernel, dim3(stream_blocks(n * 4, 256)), dim3(256), 0, s, make_model(m),
+                       reinterpret_cast<const float4 *>(in), n, range);
 }
 
 void rvb_launch_histogram_fast(const AttenuationModel & m, const rvb_impulse * in, uint64_t n, float predelay,
