@@ -204,8 +204,8 @@ std::string rvb_build_scene(const rvb_triangle * triangles, uint64_t ntriangles,
                             const rvb_float3 * vertices, uint64_t nvertices,
                             uint64_t nsurfaces, BuiltScene & out)
 {
-    if (ntriangles >= (1ull << 25))
-        return "too many triangles (limit 2^25: node references are 31-bit byte offsets of 64-byte nodes)";
+    if (ntriangles >= (1ull << 24))
+        return "too many triangles (limit 2^24: triangle byte offsets are formed with a 24-bit multiply, node references are 31-bit byte offsets)";
     out = BuiltScene();
     out.shade.resize(ntriangles);
     out.corners.resize(ntriangles);

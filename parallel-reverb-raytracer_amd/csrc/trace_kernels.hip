@@ -104,6 +104,19 @@ template <int CTRL> __device__ __forceinline__ unsigned long long dpp_u64(unsign
 template <int K> __device__ __forceinline__ float quad_bcast_f(float v) { return dpp_f<QP_BCAST(K)>(v); }
 template <int K> __device__ __forceinline__ uint32_t quad_bcast_u(uint32_t v) { return dpp_u<QP_BCAST(K)>(v); }
 
+// byte offset of leaf-order triangle i < 2^24 (rvb_build_scene's limit): one full-rate 24-bit multiply
+// (the 32-bit v_mul_lo_u32 the compiler picks for i * 48 is a quarter-rate instruction)
+__device__ __forceinline__ uint32_t tri_byte_offset(uint32_t i) { return __umul24(i, (uint32_t) sizeof(BvhTri)); }
+
+// does `pred` hold in any lane of this lane's quad?  Two DPP ORs (a 64-bit ballot masked per quad costs 64-bit VALU compares)
+__device__ __forceinline__ bool quad_any(bool pred)
+{
+    uint32_t p = pred ? 1u : 0u;
+    p |= (uint32_t) __builtin_amdgcn_mov_dpp((int) p, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
+    p |= (uint32_t) __builtin_amdgcn_mov_dpp((int) p, 0x4E, 0xF, 0xF, true);      // quad_perm [2,3,0,1]
+    return p != 0;
+}
+
 // 4-bit mask of `pred` over this lane's quad
 __device__ __forceinline__ uint32_t quad_ballot(bool pred)
 {
@@ -225,7 +238,7 @@ __device__ __forceinline__ void traverse_jobs(const SceneDev & sc, uint32_t * __
             float dist = 0.0f;
             uint32_t idx = NONE;
             if (c < count) {
-                const float4 * tp = reinterpret_cast<const float4 *>(sc.tris + first + c);
+                const float4 * tp = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sc.tris) + tri_byte_offset(first + c));
                 float4 ta = tp[0], tb = tp[1], tc = tp[2];
                 // all three loads leave before the first use: without this the compiler sinks the v0 load below the
                 // |det| test of mt_intersect and a leaf step pays two dependent round trips instead of one
@@ -234,7 +247,7 @@ __device__ __forceinline__ void traverse_jobs(const SceneDev & sc, uint32_t * __
                 idx = __float_as_uint(tc.y);
             }
             if (ANY) {
-                found = quad_ballot(c < count && dist > RVB_EPSILON && dist <= tmax) != 0;
+                found = quad_any(c < count && dist > RVB_EPSILON && dist <= tmax);
             } else {
                 // kernel.cpp:180-188 — smallest distance wins, equal distances go to the lower index.
                 // Lexicographic (distance, index) minimum over the quad's valid lanes.
@@ -379,7 +392,7 @@ __device__ __forceinline__ void traverse_jobs_vote(const SceneDev & sc, uint32_t
                 float dist = 0.0f;
                 uint32_t idx = NONE;
                 if (c < count) {
-                    const float4 * tp = reinterpret_cast<const float4 *>(tri_base + (first + c) * (uint32_t) sizeof(BvhTri));
+                    const float4 * tp = reinterpret_cast<const float4 *>(tri_base + tri_byte_offset(first + c));
                     float4 ta = tp[0], tb = tp[1], tc = tp[2];
                     asm volatile("" : "+v"(ta.x), "+v"(tb.x), "+v"(tc.x));     // all three loads leave before the first use
                     dist = mt_intersect(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), o, d);
@@ -834,7 +847,7 @@ struct ShadowJob {
         store_stream(rec + c, o);
         // inputs of findPredelay / MAX_SAMPLE (rayverb.h:49-74, rayverb.cpp:54-57) for free: an impulse
         // takes part iff any band is non-zero (kernel.cpp:524)
-        const bool nonzero = quad_ballot(c < 2 && (o.x != 0.0f || o.y != 0.0f || o.z != 0.0f || o.w != 0.0f)) != 0;
+        const bool nonzero = quad_any(c < 2 && (o.x != 0.0f || o.y != 0.0f || o.z != 0.0f || o.w != 0.0f));
         if (nonzero) {
             const float t = seconds_per_meter() * dist;
             if (t != 0.0f) tmin = fminf(tmin, t);
