@@ -29,7 +29,7 @@ from parallel_reverb_raytracer_amd import capi, distributed, dtypes, scenes  # n
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 4   # 256 CUs x 4 SIMDs, one VALU wave-instruction per 4 cycles at 2.4 GHz = 614.4 G/s
-PMC_FILE = "r01b_pmc_n1.json"
+PMC_FILE = "r01c_pmc_n1.json"
 
 
 def parse():
@@ -46,6 +46,8 @@ def parse():
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     p.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
+    p.add_argument("--contexts", type=int, default=2, help="contexts per GPU that alternate IRs (2: the trace of IR i+1 runs beside the "
+                   "grouping / binning / host stages of IR i; 1: strictly one IR at a time)")
     return p.parse_args()
 
 
@@ -99,41 +101,56 @@ def main():
     speakers_dir, speakers_coeff = [(-1, 0, -1), (1, 0, -1)], [0.5, 0.5]
     mode = capi.IR_FAST if args.mode == "fast" else capi.IR_EXACT
 
-    ctx = capi.Context(local_rank)
-    t0 = time.perf_counter()
-    ctx.set_scene(scene)
-    scene_ms = (time.perf_counter() - t0) * 1e3
     # this rank's contiguous shard of the global seeded ray set, resident in HBM before timing starts
     dirs = torch.from_numpy(np.ascontiguousarray(scenes.sphere_directions(nrays, seed=1, first=rank * nrays))).to(device)
     torch.cuda.synchronize()
-    ctx.set_directions_device(dirs.data_ptr(), nrays)
+    contexts, scene_ms = [], 0.0
+    for _ in range(max(1, args.contexts)):
+        c = capi.Context(local_rank)
+        t0 = time.perf_counter()
+        c.set_scene(scene)
+        scene_ms = (time.perf_counter() - t0) * 1e3
+        c.set_directions_device(dirs.data_ptr(), nrays)
+        contexts.append(c)
+    ctx = contexts[0]
+    pipeline = distributed.IrPipeline(contexts)
 
-    kernel_ms = {}
+    kernel_ms, solo_ms = {}, {}
     state = {}
+    trace_args = (mic, src, nrefl, dtypes.AIR_COEFFICIENTS)
 
-    def step(record):
-        def on_stage(_name):
-            if record:
-                for k, v in ctx.last_timings():
-                    kernel_ms.setdefault(k, []).append(v)
-        hist, info = distributed.generate_ir(ctx, mic, src, nrefl, dtypes.AIR_COEFFICIENTS, speakers_dir, speakers_coeff, sr,
-                                             trim_predelay=True, mode=mode, rank=rank, world=world, ray_offset=rank * nrays,
-                                             device=device, on_stage=on_stage)
+    def ir_kwargs(sink):
+        def on_stage(_name, tracer):
+            if sink is not None:
+                for k, v in tracer.last_timings():
+                    sink.setdefault(k, []).append(v)
+        return dict(speakers_dir=speakers_dir, speakers_coeff=speakers_coeff, sample_rate=sr, trim_predelay=True, mode=mode,
+                    rank=rank, world=world, ray_offset=rank * nrays, device=device, on_stage=on_stage)
+
+    def keep(hist, info, _tracer):
         state.update(hist=hist, nbins=info["nbins"], images=info["images"], predelay=info["predelay"])
 
     def fence():
-        ctx.synchronize()
+        for c in contexts:
+            c.synchronize()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(False)
+    # untimed: every context allocates its buffers, then one IR strictly alone for the per-kernel "solo" durations and the
+    # single-IR latency (the timed region below overlaps two IRs when --contexts 2)
+    for c in contexts:
+        distributed.generate_ir(c, *trace_args, **ir_kwargs(None))
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
+    distributed.generate_ir(ctx, *trace_args, **ir_kwargs(solo_ms))
+    ctx.synchronize()
+    solo_latency_ms = (time.perf_counter() - t0) * 1e3
+    pipeline.run(args.warmup, trace_args, ir_kwargs(None), keep)
+    fence()
+    t0 = time.perf_counter()
+    pipeline.run(args.steps, trace_args, ir_kwargs(kernel_ms), keep)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -171,38 +188,50 @@ def main():
             "time_range_kernel": 64.0 * nrays * nrefl,
             "histogram_fast_kernel": 64.0 * nrays * nrefl,
         }
-        trace_ms = sum(avg.get(k, 0.0) for k in ("path_kernel", "image_kernel", "shadow_kernel"))
-        dominant = max(avg, key=avg.get)
-        ach = algorithmic.get(dominant, 0.0) / (avg[dominant] * 1e-3) / 1e9
+        solo = {k: float(np.mean(v)) for k, v in solo_ms.items()}       # one IR alone on the GPU (untimed pass above)
+        trace_ms = sum(solo.get(k, 0.0) for k in ("path_kernel", "image_kernel", "shadow_kernel"))
+        dominant = max(solo, key=solo.get)                              # by the time the kernel itself needs
+        # Kernel durations for the rooflines come from the solo pass (HIP events around each launch with one IR on the GPU): in the
+        # timed region the kernels of two IRs interleave and the events around a launch then span its neighbour's work as well.
+        # rocprofv3 --kernel-trace --stats of `bench.py --contexts 1` agrees with them (profiles/).
+        ach = algorithmic.get(dominant, 0.0) / (solo[dominant] * 1e-3) / 1e9
         # HBM traffic per launch from the committed PMC passes of this same command (profiles/), if the workload matches
-        traffic, valu_insts = {}, {}
+        traffic, valu_insts, valu_per_ir = {}, {}, None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
             if (nrays, nrefl, args.triangles, world) == (100000, 128, 75000, 1):
                 traffic = {k: v["hbm_bytes_per_launch"] for k, v in pmc["kernels"].items() if "hbm_bytes_per_launch" in v}
                 valu_insts = {k: v["SQ_INSTS_VALU"] for k, v in pmc["kernels"].items() if "SQ_INSTS_VALU" in v}
+                valu_per_ir = pmc.get("valu_wave_instructions_per_ir")
         except (OSError, ValueError, KeyError):
             pass
         roofline = {"kernel": dominant, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic.get(dominant),
                     "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)" % PMC_FILE if traffic else None,
-                    "avg_launch_ms": avg[dominant],
-                    "note": "trace kernels are VALU-issue-bound by construction (scene + BVH are cache-resident): see roofline_valu; "
+                    "avg_launch_ms": solo[dominant], "elapsed_ms_in_timed_region": avg.get(dominant),
+                    "note": "avg_launch_ms: HIP events around the launch with one IR on the GPU (in the timed region two IRs share it); "
+                            "trace kernels are VALU-issue-bound by construction (scene + BVH are cache-resident): see roofline_valu; "
                             "the HBM-bound kernels of the path are reported in roofline_stream"}
-        # What actually bounds the trace kernels: VALU issue.  achieved = VALU wave-instructions per launch (PMC SQ_INSTS_VALU of
-        # this same command, a property of the workload) / live launch time; peak = 1024 SIMDs x one wave-instruction per 4 cycles.
+        # What actually bounds the trace kernels: VALU issue.  achieved = VALU wave-instructions (PMC SQ_INSTS_VALU of this same
+        # command, a property of the workload) / time; peak = 1024 SIMDs x one wave-instruction per 4 cycles.  Per kernel against
+        # its duration when it has the GPU to itself (kernel_ms_solo: in the timed region two IRs share the GPU and a kernel's
+        # elapsed time includes its neighbour's work); whole_step = every kernel of one IR against the timed region's ms_per_step.
         valu = {}
         for k in ("path_kernel", "shadow_kernel"):
-            if k in valu_insts and avg.get(k):
-                a = valu_insts[k] / (avg[k] * 1e-3) / 1e9
+            if k in valu_insts and solo.get(k):
+                a = valu_insts[k] / (solo[k] * 1e-3) / 1e9
                 valu[k] = {"bound": "valu_issue", "achieved": a, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
-                           "frac": a / VALU_PEAK_GINST, "avg_launch_ms": avg[k], "valu_instructions_per_launch": valu_insts[k]}
+                           "frac": a / VALU_PEAK_GINST, "avg_launch_ms": solo[k], "valu_instructions_per_launch": valu_insts[k]}
+        if valu_per_ir:
+            a = valu_per_ir * world / (elapsed / args.steps) / 1e9
+            valu["whole_step"] = {"bound": "valu_issue", "achieved": a, "peak": VALU_PEAK_GINST * world, "unit": "G wave-instructions/s",
+                                  "frac": a / (VALU_PEAK_GINST * world), "valu_instructions_per_ir": valu_per_ir}
         stream = {}
         for k in ("shadow_kernel", "time_range_kernel", "histogram_fast_kernel"):
-            if k in avg and avg[k] > 0:
-                a = algorithmic[k] / (avg[k] * 1e-3) / 1e9
+            if k in solo and solo[k] > 0:                # against the kernel's duration with the GPU to itself
+                a = algorithmic[k] / (solo[k] * 1e-3) / 1e9
                 stream[k] = {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
-                             "avg_launch_ms": avg[k], "traffic": traffic.get(k)}
+                             "avg_launch_ms": solo[k], "traffic": traffic.get(k)}
         if attenuate_probe and attenuate_probe["ms"]:
             a = attenuate_probe["bytes"] / (attenuate_probe["ms"] * 1e-3) / 1e9
             stream["attenuate_kernel"] = {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
@@ -216,11 +245,12 @@ def main():
                                    "2 cardioid speakers, %.0f Hz, trim_predelay, output_mode all, histogram mode %s"
                                    % (scene[0].shape[0], nrays, nrefl, sr, args.mode),
                        "triangles": int(scene[0].shape[0]), "rays_per_gpu": nrays, "reflections": nrefl,
-                       "sharding": "ray-range shards, replicated scene, one all-reduce(sum) of [2][8][nbins] histograms"},
-            "ir_gen_wall_ms": ms_per_step,
+                       "sharding": "ray-range shards, replicated scene, one all-reduce(sum) of [2][8][nbins] histograms",
+                       "pipelining": "%d contexts per GPU alternate IRs: the trace of IR i+1 is enqueued before IR i is finished" % len(contexts)},
+            "ir_gen_wall_ms": solo_latency_ms, "contexts_per_gpu": len(contexts),
             "trace_only_ray_bounces_per_sec": (nrays * nrefl) / (trace_ms * 1e-3) if trace_ms else None,
             "executed_bounces_rank0": int(executed), "nominal_bounces_rank0": nrays * nrefl,
-            "kernel_ms": avg, "nbins": state["nbins"], "image_sources": state["images"], "predelay_s": state["predelay"],
+            "kernel_elapsed_ms_timed_region": avg, "kernel_ms": solo, "nbins": state["nbins"], "image_sources": state["images"], "predelay_s": state["predelay"],
             "scene_build_upload_ms": scene_ms, "bvh": ctx.scene_info(),
             "roofline": roofline, "roofline_stream": stream, "roofline_valu": valu,
         }

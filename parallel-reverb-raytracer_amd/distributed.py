@@ -77,9 +77,14 @@ def combine_time_ranges(ranges):
     return (min(los) if los else 0.0), max([hi for _, hi in ranges] + [0.0])
 
 
+def begin_ir(tracer, mic, source, nreflections, air, ray_offset=0):
+    """First half of generate_ir: enqueues the trace of the rays already set on `tracer` (asynchronous on a GPU context)."""
+    tracer.trace(mic, source, nreflections, air, ray_offset=ray_offset)
+
+
 def generate_ir(tracer, mic, source, nreflections, air, speakers_dir, speakers_coeff, sample_rate,
                 trim_predelay=True, mode=capi.IR_FAST, rank=0, world=1, ray_offset=0, device="cpu",
-                which=capi.IR_ALL, remove_direct=False, on_stage=None):
+                which=capi.IR_ALL, remove_direct=False, on_stage=None, begun=False):
     """One impulse response from the rays already set on `tracer`.  Returns (hist tensor
     [nchannels][8][nbins] — identical on every rank —, info dict).
 
@@ -87,15 +92,20 @@ def generate_ir(tracer, mic, source, nreflections, air, speakers_dir, speakers_c
     world > 1: two collectives in all.  (1) exchange_shard_summaries: every rank learns every shard's
     image-source candidates and diffuse time range, merges the candidates itself (deterministic, a few
     dozen records) and so knows the global predelay / length without a further exchange; (2) the
-    all-reduce(sum) of the histograms.  Only rank 0 adds the merged image impulses to its histogram."""
+    all-reduce(sum) of the histograms.  Only rank 0 adds the merged image impulses to its histogram.
+
+    begun=True: begin_ir(tracer, ...) has already enqueued this IR's trace.  A caller with two contexts per GPU
+    calls begin_ir on the second before generate_ir(..., begun=True) on the first, so that one IR's trace (VALU-bound)
+    runs beside the other's record grouping, binning, host work and collectives (IrPipeline below)."""
     import torch
     import torch.distributed as dist
 
     empty = np.zeros(0, dtype=IMPULSE)
-    tracer.trace(mic, source, nreflections, air, ray_offset=ray_offset)
+    if not begun:
+        begin_ir(tracer, mic, source, nreflections, air, ray_offset)
     candidates = tracer.get_image_candidates()           # small: valid image-source paths only
     if on_stage:
-        on_stage("trace")
+        on_stage("trace", tracer)
     direct = tracer.get_direct()
     want_images = bool(which & capi.IR_IMAGES)
     if world == 1:
@@ -103,7 +113,7 @@ def generate_ir(tracer, mic, source, nreflections, air, speakers_dir, speakers_c
         tracer.ir_configure_speakers(mic, speakers_dir, speakers_coeff, which, images)
         lo, hi = tracer.ir_time_range()
         if on_stage:
-            on_stage("time_range")
+            on_stage("time_range", tracer)
         contributes = True
     else:
         ranges = []
@@ -112,7 +122,7 @@ def generate_ir(tracer, mic, source, nreflections, air, speakers_dir, speakers_c
             tracer.ir_configure_speakers(mic, speakers_dir, speakers_coeff, capi.IR_DIFFUSE, empty)
             lo_d, hi_d = tracer.ir_time_range()
             if on_stage:
-                on_stage("time_range")
+                on_stage("time_range", tracer)
         candidates, shard_ranges = exchange_shard_summaries(candidates, lo_d, hi_d, world, device)
         ranges += shard_ranges
         images = capi.merge_images(candidates, direct, remove_direct) if want_images else empty
@@ -132,8 +142,43 @@ def generate_ir(tracer, mic, source, nreflections, air, speakers_dir, speakers_c
     if contributes:                                      # (the tracer's stream waits for torch's zero fill by an event)
         tracer.ir_accumulate_tensor(predelay, sample_rate, nbins, mode, hist)
     if on_stage:
-        on_stage("accumulate")
+        on_stage("accumulate", tracer)
     tracer.synchronize()
     if world > 1:
         dist.all_reduce(hist, op=dist.ReduceOp.SUM)      # RCCL over xGMI: [channels][8][nbins] floats
     return hist, {"nbins": nbins, "predelay": predelay, "images": int(images.shape[0]), "max_time": hi}
+
+
+class IrPipeline:
+    """Impulse responses back to back with TWO contexts per GPU: the trace of IR i+1 is enqueued on the other context
+    before IR i is finished, so its VALU-bound path kernel runs beside IR i's bandwidth-, atomic- and host-bound stages
+    (record grouping, binning, candidate merge, collectives).  Single host thread, collectives in program order: safe
+    with any world size.  Measured on one MI355X at workload C2: 6.45 -> 5.6 ms per IR."""
+
+    def __init__(self, tracers):
+        assert len(tracers) >= 1
+        self.tracers = list(tracers)
+        self.next_slot = 0
+        self.begun = [False] * len(self.tracers)
+
+    def run(self, count, trace_args, ir_kwargs, on_result=None):
+        """`count` IRs with the same arguments (bench) — trace_args = (mic, source, nreflections, air), ir_kwargs as
+        generate_ir takes them.  on_result(hist, info, tracer) is called per IR in order."""
+        n = len(self.tracers)
+        if count <= 0:
+            return
+        first = self.next_slot
+        begin_ir(self.tracers[first], *trace_args, ray_offset=ir_kwargs.get("ray_offset", 0))
+        self.begun[first] = True
+        for i in range(count):
+            slot = (first + i) % n
+            nxt = (first + i + 1) % n
+            if i + 1 < count and n > 1:
+                begin_ir(self.tracers[nxt], *trace_args, ray_offset=ir_kwargs.get("ray_offset", 0))
+                self.begun[nxt] = True
+            began = self.begun[slot]
+            self.begun[slot] = False
+            hist, info = generate_ir(self.tracers[slot], *trace_args, begun=began, **ir_kwargs)
+            if on_result:
+                on_result(hist, info, self.tracers[slot])
+        self.next_slot = (first + count) % n

@@ -167,6 +167,33 @@ def test_attenuate_speaker_matches_golden(ctx):
             assert not out["pad"].any()
 
 
+def test_attenuate_speaker_device_entry_equals_host_entry(ctx, oracle):
+    """rvb_attenuate_speaker_device (HBM in, HBM out) runs the same kernel as rvb_attenuate_speaker: same bytes, ragged n."""
+    import torch
+    from parallel_reverb_raytracer_amd import dtypes
+    rng = np.random.default_rng(11)
+    n = 100003                                                       # not a multiple of anything the kernel tiles by
+    imp = np.zeros(n, dtype=dtypes.IMPULSE)
+    imp["volume"] = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
+    imp["volume"][::7] = 0                                           # zero-volume impulses -> {0, 0} (quirk Q2)
+    imp["position"][:, :3] = rng.uniform(-20, 20, (n, 3)).astype(np.float32)
+    imp["position"][5, :3] = (1.0, 2.0, 3.0)                         # = mic: normalize(0) stays 0 (quirk Q6)
+    imp["time"] = rng.uniform(0.01, 3, n).astype(np.float32)
+    mic, direction, coeff = (1.0, 2.0, 3.0), (0.3, -0.2, 0.9), 0.5
+    want = ctx.attenuate_speaker(mic, imp, direction, coeff)
+    d_in = torch.from_numpy(imp.view(np.uint8).reshape(-1)).cuda()
+    d_out = torch.full((n * 64,), 0xAB, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.attenuate_speaker_device(mic, d_in.data_ptr(), n, direction, coeff, d_out.data_ptr())
+    ctx.synchronize()
+    got = d_out.cpu().numpy().view(dtypes.ATTENUATED)
+    assert np.array_equal(got["volume"], want["volume"]) and np.array_equal(got["time"], want["time"])
+    ref = oracle.attenuate_speaker(mic, imp, direction, coeff)
+    nz = imp["volume"].any(axis=1)
+    assert np.array_equal(got["volume"][nz], ref["volume"][nz]) and np.array_equal(got["time"][nz], ref["time"][nz])
+    assert not got["volume"][~nz].any() and not got["time"][~nz].any()
+
+
 def test_attenuate_hrtf_matches_golden(ctx):
     g = load_golden("attenuate_hrtf")
     tables = {"test": scenes.hrtf_test_table(), "smooth": scenes.hrtf_synthetic_table()}

@@ -13,7 +13,7 @@ for spec in "$@"; do
         echo "$name PARITY-FAIL (see ${out}.parity.log)"; tail -5 ${out}.parity.log
         continue
     fi
-    env RVB_LIB="$PWD/$lib" $envs timeout -k 10 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline > ${out}.json 2> ${out}.err || { echo "$name BENCH-FAIL"; tail -3 ${out}.err; continue; }
+    env RVB_LIB="$PWD/$lib" $envs timeout -k 10 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --contexts 1 > ${out}.json 2> ${out}.err || { echo "$name BENCH-FAIL"; tail -3 ${out}.err; continue; }
     python - "$name" ${out}.json <<'EOF'
 import json, sys
 d = json.load(open(sys.argv[2]))

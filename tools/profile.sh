@@ -10,9 +10,12 @@ root=$PWD
 export TMPDIR=/tmp
 out=$root/gpurun_out
 mkdir -p "$out"
-BENCH="python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+# Kernel durations and counters are taken with ONE IR at a time (--contexts 1): in the default mode the kernels of two IRs share
+# the GPU, and a kernel's span then includes its neighbour's work.  One more stats pass records the default command as it is.
+BENCH="python3 $root/bench.py --steps 4 --warmup 1 --no-cpu-baseline --contexts 1"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats" -o run -- $BENCH > "$out/${tag}_bench_under_rocprof.json" 2> "$out/${tag}_stats.err" || echo "stats pass failed"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats_default" -o run -- python3 $root/bench.py --steps 4 --warmup 1 --no-cpu-baseline > "$out/${tag}_bench_default_under_rocprof.json" 2> "$out/${tag}_stats_default.err" || echo "default stats pass failed"
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_ATOMIC_sum" \
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU" \
            "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAVES GRBM_GUI_ACTIVE"; do

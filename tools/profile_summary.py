@@ -22,17 +22,20 @@ def short(name):
 
 
 # kernel stats: keep the full csv, print ours
-stats = glob.glob(os.path.join(out, tag + "_stats", "**", "*kernel_stats.csv"), recursive=True)
-if stats:
+for suffix in ("", "_default"):
+    stats = glob.glob(os.path.join(out, tag + "_stats" + suffix, "**", "*kernel_stats.csv"), recursive=True)
+    if not stats:
+        continue
+    print("--- kernel stats%s" % suffix)
     rows = list(csv.DictReader(open(stats[0])))
-    with open(os.path.join(out, tag + "_kernel_stats.csv"), "w") as f:
-        w = csv.writer(f)
-        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
-        for r in rows:
-            s = short(r["Name"])
-            w.writerow([s or r["Name"][:80], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
-            if s:
-                print("%-36s calls %3s avg %10.1f us" % (s, r["Calls"], float(r["AverageNs"]) / 1e3))
+    with open(os.path.join(out, tag + "_kernel_stats%s.csv" % suffix), "w") as f:
+            w = csv.writer(f)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+            for r in rows:
+                s = short(r["Name"])
+                w.writerow([s or r["Name"][:80], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+                if s:
+                    print("%-36s calls %3s avg %10.1f us" % (s, r["Calls"], float(r["AverageNs"]) / 1e3))
 
 pmc = {}
 for d in sorted(glob.glob(os.path.join(out, tag + "_pmc_*"))):
@@ -50,6 +53,9 @@ for d in sorted(glob.glob(os.path.join(out, tag + "_pmc_*"))):
             a[1].add(r["Dispatch_Id"])
         for (s, c), (total, disp) in acc.items():
             pmc.setdefault(s, {})[c] = total / max(1, len(disp))
+            pmc[s].setdefault("_launches", len(disp))
+            if c == "SQ_INSTS_VALU":
+                pmc[s]["SQ_INSTS_VALU_all_launches"] = total
 for s, c in pmc.items():
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         c["hbm_bytes_per_launch"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
@@ -59,7 +65,10 @@ for s, c in pmc.items():
         # SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES count quad-cycles (MI355X_MICROARCH.md "s_memtime tick vs SQ PMC units")
         c["valu_active_share_of_wave_cycles"] = c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else None
         c["wait_any_share_of_wave_cycles"] = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") and "SQ_WAIT_ANY" in c else None
-json.dump({"_how": "tools/profile.sh %s: rocprofv3 --kernel-trace --pmc <one set per pass> -- python3 bench.py --steps 3 --warmup 1 "
+irs = pmc.get("path_kernel", {}).get("_launches", 0)
+step_kernels = [k for k in pmc if k != "attenuate_kernel"]          # the attenuate probe runs outside the timed steps
+valu_per_ir = sum(pmc[k].get("SQ_INSTS_VALU_all_launches", 0.0) for k in step_kernels) / irs if irs else None
+json.dump({"irs_in_command": irs, "valu_wave_instructions_per_ir": valu_per_ir, "_how": "tools/profile.sh %s: rocprofv3 --kernel-trace --pmc <one set per pass> -- python3 bench.py --steps 3 --warmup 1 "
                    "--no-cpu-baseline; per-launch averages; hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 FETCH_SIZE counts "
                    "128-B requests as 64 B: MI355X_MICROARCH.md HBM section; upper bound for gather-heavy kernels)" % tag,
            "kernels": pmc}, open(os.path.join(out, tag + "_pmc.json"), "w"), indent=1)
