@@ -94,3 +94,53 @@ def test_time_range_combination():
     assert distributed.combine_time_ranges([(0.0, 0.0), (0.5, 2.0), (0.25, 1.0)]) == (0.25, 2.0)
     assert distributed.combine_time_ranges([(0.0, 0.0)]) == (0.0, 0.0)
     assert distributed.combine_time_ranges([]) == (0.0, 0.0)
+
+
+def _pipeline_worker(rank, world, port, out_dir, total_rays, nrefl):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import rvb_import
+    rvb_import.load()
+    import torch.distributed as dist
+    import pyoracle
+    from oracle_tracer import OracleTracer
+    from parallel_reverb_raytracer_amd import capi, distributed, dtypes, scenes
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    scene, info = scenes.cathedral(1200)
+    first, count = distributed.shard_range(total_rays, rank, world)
+    dirs = scenes.sphere_directions(count, seed=9, first=first)
+    tracers = [OracleTracer(pyoracle.Oracle("port"), scene, dirs) for _ in range(2)]
+    got = []
+    pipe = distributed.IrPipeline(tracers)
+    kwargs = dict(speakers_dir=[(-1, 0, -1), (1, 0, -1)], speakers_coeff=[0.5, 0.5], sample_rate=44100.0, trim_predelay=True,
+                  mode=capi.IR_EXACT, rank=rank, world=world, ray_offset=first, device="cpu")
+    args = (info["mic"], info["source"], nrefl, dtypes.AIR_COEFFICIENTS)
+    pipe.run(3, args, kwargs, lambda hist, meta, tracer: got.append((hist.numpy().copy(), meta["nbins"], tracers.index(tracer))))
+    pipe.run(2, args, kwargs, lambda hist, meta, tracer: got.append((hist.numpy().copy(), meta["nbins"], tracers.index(tracer))))
+    np.savez(os.path.join(out_dir, "pipe_rank%d_of%d.npz" % (rank, world)), hists=np.stack([g[0] for g in got]),
+             slots=np.array([g[2] for g in got]))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_ir_pipeline_alternates_contexts_and_changes_nothing(tmp_path, oracle):
+    """IrPipeline (two contexts, the next IR's trace enqueued before the current IR is finished) returns, IR by IR, what
+    generate_ir returns — with one rank and with two gloo ranks (collectives stay in program order)."""
+    import torch.multiprocessing as mp
+    total_rays, nrefl = 64, 8
+    _worker(0, 1, 0, str(tmp_path), total_rays, nrefl)
+    plain = np.load(os.path.join(str(tmp_path), "rank0_of1.npz"))["hist"]
+    _pipeline_worker(0, 1, 0, str(tmp_path), total_rays, nrefl)
+    one = np.load(os.path.join(str(tmp_path), "pipe_rank0_of1.npz"))
+    assert list(one["slots"]) == [0, 1, 0, 1, 0]                       # alternates, and continues across run() calls
+    assert all(np.array_equal(h, plain) for h in one["hists"])
+    mp.spawn(_pipeline_worker, args=(2, _free_port(), str(tmp_path), total_rays, nrefl), nprocs=2, join=True)
+    two = [np.load(os.path.join(str(tmp_path), "pipe_rank%d_of2.npz" % r)) for r in (0, 1)]
+    assert np.array_equal(two[0]["hists"], two[1]["hists"])
+    assert all(np.array_equal(h, two[0]["hists"][0]) for h in two[0]["hists"])
+    a, b = plain.astype(np.float64), two[0]["hists"][0].astype(np.float64)
+    assert (np.abs(a - b) <= 1e-5 * (np.abs(a).max(axis=2, keepdims=True) + 1e-30)).all()
