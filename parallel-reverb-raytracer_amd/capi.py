@@ -48,6 +48,15 @@ def load_library():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("%s not built: run __graft_entry__.build() (no CPU fallback exists)" % LIB_PATH)
+        # torch brings its own copy of the HIP runtime; if this library's copy initialises the GPU first, torch.cuda later reports
+        # "No HIP GPUs are available" (two runtimes in one process, load-order dependent).  Let torch go first when it is there:
+        # device tensors handed over by pointer (bench.py, distributed.py) need it anyway.
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except ImportError:
+            pass
         lib = ctypes.CDLL(LIB_PATH)
         lib.rvb_last_error.restype = ctypes.c_char_p
         lib.rvb_last_error.argtypes = [_vp]
