@@ -128,6 +128,27 @@ def test_grazing_rays_match_brute_force(ctx, oracle, height, slope):
     assert_impulses_equal(ctx.get_raw_images(False), oracle.collect_images(image, index, False), "grazing images")
 
 
+def test_many_surfaces_take_the_global_memory_path(ctx, oracle):
+    """More surfaces than the quad kernels stage in LDS (rvb_lds_surfaces budget): the path / shadow instantiations that read
+    the coefficient rows from HBM must give the same bytes."""
+    from parallel_reverb_raytracer_amd.dtypes import SURFACE, aligned_zeros
+    tris, verts, _ = scenes.rotated_square_room(n=6)                 # 432 triangles
+    rng = np.random.default_rng(21)
+    surfaces = aligned_zeros(300, SURFACE)                           # 300 x 64 B = 19 KB > the 5 KB per-workgroup budget
+    surfaces["specular"] = rng.uniform(0.5, 0.99, (300, 8)).astype(np.float32)
+    surfaces["diffuse"] = rng.uniform(0.3, 0.95, (300, 8)).astype(np.float32)
+    tris = tris.copy()
+    tris["surface"] = rng.integers(0, 300, tris.shape[0])
+    scene = (tris, verts, surfaces)
+    mic, src = (0.5, 2.0, 0.25), (-3.0, 4.0, 2.0)
+    dirs = scenes.sphere_directions(777, seed=23)                    # ragged: not a multiple of the 16 rays per wave
+    ctx.set_scene(scene)
+    ctx.raytrace(mic, src, dirs, 19, AIR_COEFFICIENTS)
+    want, image, index = oracle.raytrace(scene, mic, src, dirs, 19, AIR_COEFFICIENTS)
+    assert_impulses_equal(ctx.get_raw_diffuse(), want, "300 surfaces")
+    assert_impulses_equal(ctx.get_raw_images(False), oracle.collect_images(image, index, False), "300 surfaces images")
+
+
 def test_edge_cases_empty_and_ragged(ctx, oracle):
     scene = scenes.rotated_square_room(n=1)
     ctx.set_scene(scene)

@@ -102,7 +102,7 @@ struct Sim {
         const BvhNode & n = bs.nodes[q.ref >> RVB_BVH_NODE_SHIFT];
         const int lvl = level.empty() ? 0 : level[q.ref >> RVB_BVH_NODE_SHIFT];
         ++by_level[lvl];
-        const float lim = limit(q), neg_cull = -cull_abs;
+        const float lim = limit(q), neg_cull = getenv("TRAVSIM_ZERO_CLAMP") ? 0.0f : -cull_abs;
         bool ok[4]; float tn[4];
         int nok = 0;
         for (int c = 0; c < 4; ++c) {
