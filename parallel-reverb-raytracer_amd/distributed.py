@@ -77,14 +77,36 @@ def combine_time_ranges(ranges):
     return (min(los) if los else 0.0), max([hi for _, hi in ranges] + [0.0])
 
 
+class SpeakerModel:
+    """Microphone model of reference kernel `attenuate` (cardioid-family speakers, config.h AttenuationModel::SPEAKER)."""
+
+    def __init__(self, directions, coefficients):
+        self.directions, self.coefficients = directions, coefficients
+        self.nchannels = len(coefficients)
+
+    def configure(self, tracer, mic, which, images):
+        tracer.ir_configure_speakers(mic, self.directions, self.coefficients, which, images)
+
+
+class HrtfModel:
+    """Listener model of reference kernel `hrtf` (AttenuationModel::HRTF): table [2][360][180][8], facing and up vectors."""
+
+    def __init__(self, table, facing, up):
+        self.table, self.facing, self.up = table, facing, up
+        self.nchannels = 2
+
+    def configure(self, tracer, mic, which, images):
+        tracer.ir_configure_hrtf(mic, self.table, self.facing, self.up, which, images)
+
+
 def begin_ir(tracer, mic, source, nreflections, air, ray_offset=0):
     """First half of generate_ir: enqueues the trace of the rays already set on `tracer` (asynchronous on a GPU context)."""
     tracer.trace(mic, source, nreflections, air, ray_offset=ray_offset)
 
 
-def generate_ir(tracer, mic, source, nreflections, air, speakers_dir, speakers_coeff, sample_rate,
+def generate_ir(tracer, mic, source, nreflections, air, speakers_dir=None, speakers_coeff=None, sample_rate=44100.0,
                 trim_predelay=True, mode=capi.IR_FAST, rank=0, world=1, ray_offset=0, device="cpu",
-                which=capi.IR_ALL, remove_direct=False, on_stage=None, begun=False):
+                which=capi.IR_ALL, remove_direct=False, on_stage=None, begun=False, model=None):
     """One impulse response from the rays already set on `tracer`.  Returns (hist tensor
     [nchannels][8][nbins] — identical on every rank —, info dict).
 
@@ -101,6 +123,8 @@ def generate_ir(tracer, mic, source, nreflections, air, speakers_dir, speakers_c
     import torch.distributed as dist
 
     empty = np.zeros(0, dtype=IMPULSE)
+    if model is None:                                    # the two-list form: speakers (what bench.py and the reference demo configs use)
+        model = SpeakerModel(speakers_dir, speakers_coeff)
     if not begun:
         begin_ir(tracer, mic, source, nreflections, air, ray_offset)
     candidates = tracer.get_image_candidates()           # small: valid image-source paths only
@@ -110,7 +134,7 @@ def generate_ir(tracer, mic, source, nreflections, air, speakers_dir, speakers_c
     want_images = bool(which & capi.IR_IMAGES)
     if world == 1:
         images = capi.merge_images(candidates, direct, remove_direct) if want_images else empty
-        tracer.ir_configure_speakers(mic, speakers_dir, speakers_coeff, which, images)
+        model.configure(tracer, mic, which, images)
         lo, hi = tracer.ir_time_range()
         if on_stage:
             on_stage("time_range", tracer)
@@ -119,7 +143,7 @@ def generate_ir(tracer, mic, source, nreflections, air, speakers_dir, speakers_c
         ranges = []
         lo_d = hi_d = 0.0
         if which & capi.IR_DIFFUSE:                      # this shard's diffuse impulses alone
-            tracer.ir_configure_speakers(mic, speakers_dir, speakers_coeff, capi.IR_DIFFUSE, empty)
+            model.configure(tracer, mic, capi.IR_DIFFUSE, empty)
             lo_d, hi_d = tracer.ir_time_range()
             if on_stage:
                 on_stage("time_range", tracer)
@@ -127,18 +151,18 @@ def generate_ir(tracer, mic, source, nreflections, air, speakers_dir, speakers_c
         ranges += shard_ranges
         images = capi.merge_images(candidates, direct, remove_direct) if want_images else empty
         if images.shape[0]:                              # the merged images' own range, the same on every rank
-            tracer.ir_configure_speakers(mic, speakers_dir, speakers_coeff, capi.IR_IMAGES, images)
+            model.configure(tracer, mic, capi.IR_IMAGES, images)
             ranges.append(tracer.ir_time_range())
         lo, hi = combine_time_ranges(ranges)
         mine = which if rank == 0 else (which & capi.IR_DIFFUSE)
         contributes = mine != 0
         if contributes:
-            tracer.ir_configure_speakers(mic, speakers_dir, speakers_coeff, mine, images if rank == 0 else empty)
+            model.configure(tracer, mic, mine, images if rank == 0 else empty)
         if rank != 0:
             images = empty
     predelay = lo if trim_predelay else 0.0
     nbins = tracer.ir_bins(hi, predelay, sample_rate)
-    hist = torch.zeros((len(speakers_coeff), 8, nbins), device=device, dtype=torch.float32)
+    hist = torch.zeros((model.nchannels, 8, nbins), device=device, dtype=torch.float32)
     if contributes:                                      # (the tracer's stream waits for torch's zero fill by an event)
         tracer.ir_accumulate_tensor(predelay, sample_rate, nbins, mode, hist)
     if on_stage:
@@ -164,21 +188,30 @@ class IrPipeline:
     def run(self, count, trace_args, ir_kwargs, on_result=None):
         """`count` IRs with the same arguments (bench) — trace_args = (mic, source, nreflections, air), ir_kwargs as
         generate_ir takes them.  on_result(hist, info, tracer) is called per IR in order."""
+        self.run_jobs([(trace_args, ir_kwargs)] * count, on_result)
+
+    def run_jobs(self, jobs, on_result=None):
+        """One IR per job = (trace_args, ir_kwargs), e.g. the source / listener pairs of a hall (BASELINE config C5): every
+        context must hold the same scene and rays.  Results arrive in job order."""
         n = len(self.tracers)
-        if count <= 0:
+        if not jobs:
             return
         first = self.next_slot
-        begin_ir(self.tracers[first], *trace_args, ray_offset=ir_kwargs.get("ray_offset", 0))
-        self.begun[first] = True
-        for i in range(count):
+
+        def begin(k):
+            slot = (first + k) % n
+            trace_args, ir_kwargs = jobs[k]
+            begin_ir(self.tracers[slot], *trace_args, ray_offset=ir_kwargs.get("ray_offset", 0))
+            self.begun[slot] = True
+
+        begin(0)
+        for i, (trace_args, ir_kwargs) in enumerate(jobs):
             slot = (first + i) % n
-            nxt = (first + i + 1) % n
-            if i + 1 < count and n > 1:
-                begin_ir(self.tracers[nxt], *trace_args, ray_offset=ir_kwargs.get("ray_offset", 0))
-                self.begun[nxt] = True
+            if i + 1 < len(jobs) and n > 1:
+                begin(i + 1)
             began = self.begun[slot]
             self.begun[slot] = False
             hist, info = generate_ir(self.tracers[slot], *trace_args, begun=began, **ir_kwargs)
             if on_result:
                 on_result(hist, info, self.tracers[slot])
-        self.next_slot = (first + count) % n
+        self.next_slot = (first + len(jobs)) % n

@@ -115,3 +115,44 @@ def test_c5_hall_source_listener_pairs_hrtf(ctx, oracle):
             oracle.fix_predelay(chans[ch], pd)
             flat = oracle.flatten(chans[ch], 44100.0)
             assert np.array_equal(ir[ch][:, :flat.shape[1]], flat) and not ir[ch][:, flat.shape[1]:].any()
+
+
+def test_c5_pairs_through_the_two_context_pipeline_equal_one_at_a_time(ctx):
+    """BASELINE config C5's shape — source / listener pairs of one hall, HRTF — run as jobs of IrPipeline (the next pair's trace
+    enqueued on the second context before the current pair is finished): every pair's exact-mode IR must be bit-identical to
+    the IR of that pair computed alone."""
+    import torch
+    from parallel_reverb_raytracer_amd import capi, distributed
+    scene, _ = scenes.concert_hall(30000)
+    src, mic = scenes.source_mic_pairs(64, seed=0)
+    table = scenes.hrtf_synthetic_table()
+    nrays, nrefl, pairs = 4096, 32, [0, 9, 17, 40, 63]
+    dirs = scenes.sphere_directions(nrays, seed=3)
+    other = capi.Context(0)
+    try:
+        for c in (ctx, other):
+            c.set_scene(scene)
+            c.set_directions(dirs)
+        device = torch.device("cuda", 0)
+
+        def job(p):
+            facing = src[p] - mic[p]
+            facing = facing / np.linalg.norm(facing)
+            return ((mic[p], src[p], nrefl, AIR_COEFFICIENTS),
+                    dict(model=distributed.HrtfModel(table, facing, (0, 1, 0)), sample_rate=44100.0, trim_predelay=True,
+                         mode=capi.IR_EXACT, device=device))
+
+        alone = []
+        for p in pairs:
+            args, kwargs = job(p)
+            hist, info = distributed.generate_ir(ctx, *args, **kwargs)
+            alone.append((hist.cpu().numpy(), info["nbins"], info["images"]))
+        got = []
+        distributed.IrPipeline([ctx, other]).run_jobs([job(p) for p in pairs],
+                                                      lambda hist, info, tracer: got.append((hist.cpu().numpy(), info["nbins"], info["images"])))
+        assert len(got) == len(pairs)
+        for (h0, n0, i0), (h1, n1, i1) in zip(alone, got):
+            assert n0 == n1 and i0 == i1 and np.array_equal(h0, h1)
+        assert any(h.any() for h, _, _ in got)
+    finally:
+        other.close()

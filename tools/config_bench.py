@@ -61,6 +61,49 @@ def run(name, scene, mic, src, nrays, nrefl, model, steps=4):
     return out
 
 
+def pairs_pipelined(scene, src, mic, nrays, nrefl, npairs):
+    """C5's per-GPU share (8 of the 64 pairs): the pairs as jobs of the two-context pipeline against one at a time."""
+    from parallel_reverb_raytracer_amd import distributed
+    table = scenes.hrtf_synthetic_table()
+    dirs = torch.from_numpy(np.ascontiguousarray(scenes.sphere_directions(nrays, seed=1))).cuda()
+    torch.cuda.synchronize()
+    ctxs = []
+    for _ in range(2):
+        c = capi.Context(0)
+        c.set_scene(scene)
+        c.set_directions_device(dirs.data_ptr(), nrays)
+        ctxs.append(c)
+    device = torch.device("cuda", 0)
+
+    def job(p):
+        facing = src[p] - mic[p]
+        facing = facing / np.linalg.norm(facing)
+        return ((mic[p], src[p], nrefl, dtypes.AIR_COEFFICIENTS),
+                dict(model=distributed.HrtfModel(table, facing, (0, 1, 0)), sample_rate=44100.0, trim_predelay=True,
+                     mode=capi.IR_FAST, device=device))
+
+    jobs = [job(p) for p in range(npairs)]
+    out = {}
+    for label, tracers in (("one_at_a_time", ctxs[:1]), ("two_contexts", ctxs)):
+        pipe = distributed.IrPipeline(tracers)
+        pipe.run_jobs(jobs[:2])                              # warm-up
+        for c in ctxs:
+            c.synchronize()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pipe.run_jobs(jobs)
+        for c in ctxs:
+            c.synchronize()
+        torch.cuda.synchronize()
+        out[label + "_ms_per_pair"] = (time.perf_counter() - t0) * 1e3 / npairs
+    for c in ctxs:
+        c.close()
+    out.update({"config": "C5 per-GPU share: %d pairs, concert-hall stand-in, %d rays x %d, HRTF" % (npairs, nrays, nrefl),
+                "ray_bounces_per_sec": nrays * nrefl / (out["two_contexts_ms_per_pair"] * 1e-3), "ms_per_ir": out["two_contexts_ms_per_pair"],
+                "kernel_ms": {}})
+    return out
+
+
 def main():
     results = []
     scene, info = scenes.cathedral(75000)
@@ -70,6 +113,7 @@ def main():
     scene, _ = scenes.concert_hall(30000)
     src, mic = scenes.source_mic_pairs(64, seed=0)
     results.append(run("C5 one of 64 pairs: concert-hall stand-in, 100k rays x 128, HRTF", scene, mic[0], src[0], 100000, 128, "hrtf"))
+    results.append(pairs_pipelined(scene, src, mic, 100000, 128, 8))
     print(json.dumps(results, indent=1))
 
 

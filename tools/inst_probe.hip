@@ -1,0 +1,76 @@
+// Developer tool: issue cost of the VALU instructions the traversal loops are made of, relative to v_fma_f32, measured on the
+// GPU: N back-to-back copies on 8 independent registers per lane, 8 waves per SIMD, every CU busy.
+// hipcc --offload-arch=gfx950 -O3 -o tools/_bin/inst_probe tools/inst_probe.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+
+#define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#define BODY(NAME, ASM)                                                                              \
+    __global__ __launch_bounds__(256) void k_##NAME(float * out, int iters)                           \
+    {                                                                                                 \
+        float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;  \
+        float b = 1.0001f, c = 0.5f;                                                                  \
+        for (int i = 0; i < iters; ++i) {                                                             \
+            asm volatile(ASM(0) ASM(1) ASM(2) ASM(3) ASM(4) ASM(5) ASM(6) ASM(7)                      \
+                         ASM(0) ASM(1) ASM(2) ASM(3) ASM(4) ASM(5) ASM(6) ASM(7)                      \
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc"); \
+        }                                                                                             \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;           \
+    }
+
+#define A_FMA(n) "v_fma_f32 %" #n ", %" #n ", %8, %9\n"
+#define A_FMAMIX(n) "v_fma_mix_f32 %" #n ", %" #n ", %8, %9 op_sel_hi:[1,0,0]\n"
+#define A_PERM(n) "v_perm_b32 %" #n ", %" #n ", %8, %9\n"
+#define A_MINDPP(n) "v_min_u32_dpp %" #n ", %" #n ", %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+#define A_MOVDPP(n) "v_mov_b32_dpp %" #n ", %" #n " quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+#define A_MAX3(n) "v_max3_f32 %" #n ", %" #n ", %8, %9\n"
+#define A_ANDOR(n) "v_and_or_b32 %" #n ", %" #n ", %8, %9\n"
+#define A_BCNT(n) "v_bcnt_u32_b32 %" #n ", %" #n ", %8\n"
+#define A_CNDMASK(n) "v_cndmask_b32 %" #n ", %" #n ", %8, vcc\n"
+#define A_CMP(n) "v_cmp_lt_f32 vcc, %" #n ", %8\n"
+#define A_LSHLADD(n) "v_lshl_add_u32 %" #n ", %" #n ", 2, %8\n"
+#define A_MULLO(n) "v_mul_lo_u32 %" #n ", %" #n ", %8\n"
+#define A_MUL24(n) "v_mul_u32_u24 %" #n ", %" #n ", %8\n"
+#define A_BITOP3(n) "v_bitop3_b32 %" #n ", %" #n ", %8, %9 bitop3:0x32\n"
+#define A_CVT(n) "v_cvt_f32_f16 %" #n ", %" #n "\n"
+#define A_RCP(n) "v_rcp_f32 %" #n ", %" #n "\n"
+#define A_SQRT(n) "v_sqrt_f32 %" #n ", %" #n "\n"
+#define A_MIN(n) "v_min_f32 %" #n ", %" #n ", %8\n"
+#define A_PKMUL(n) "v_pk_mul_f32 %" #n ", %" #n ", %8\n"
+#define A_DIVFIX(n) "v_div_fixup_f32 %" #n ", %" #n ", %8, %9\n"
+#define A_BPERM(n) "ds_bpermute_b32 %" #n ", %8, %" #n "\ns_waitcnt lgkmcnt(0)\n"
+
+BODY(fma, A_FMA) BODY(fma_mix, A_FMAMIX) BODY(perm, A_PERM) BODY(min_dpp, A_MINDPP) BODY(mov_dpp, A_MOVDPP) BODY(max3, A_MAX3)
+BODY(and_or, A_ANDOR) BODY(bcnt, A_BCNT) BODY(cndmask, A_CNDMASK) BODY(cmp, A_CMP) BODY(lshl_add, A_LSHLADD) BODY(mul_lo, A_MULLO)
+BODY(mul_u24, A_MUL24) BODY(bitop3, A_BITOP3) BODY(cvt_f16, A_CVT) BODY(rcp, A_RCP) BODY(sqrt, A_SQRT) BODY(min, A_MIN)
+BODY(div_fixup, A_DIVFIX) BODY(bpermute, A_BPERM)
+
+template <class K> float run(K kernel, float * out)
+{
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    float best = 1e9f;
+    for (int r = 0; r < 4; ++r) {
+        hipEventRecord(a);
+        hipLaunchKernelGGL(kernel, dim3(256 * 8), dim3(256), 0, 0, out, 4096);      // 8 blocks x 4 waves per CU = 8 waves per SIMD
+        hipEventRecord(b);
+        hipEventSynchronize(b);
+        float ms;
+        hipEventElapsedTime(&ms, a, b);
+        if (r && ms < best) best = ms;
+    }
+    return best;
+}
+
+int main()
+{
+    float * out;
+    hipMalloc(&out, 256 * 8 * 256 * sizeof(float));
+    const float base = run(k_fma, out);
+    printf("v_fma_f32        %.3f ms = 1.00\n", base);
+#define SHOW(NAME) printf("%-16s %.3f ms = %.2f\n", #NAME, run(k_##NAME, out), run(k_##NAME, out) / base);
+    SHOW(fma_mix) SHOW(perm) SHOW(min_dpp) SHOW(mov_dpp) SHOW(max3) SHOW(and_or) SHOW(bcnt) SHOW(cndmask) SHOW(cmp) SHOW(lshl_add)
+    SHOW(mul_lo) SHOW(mul_u24) SHOW(bitop3) SHOW(cvt_f16) SHOW(rcp) SHOW(sqrt) SHOW(min) SHOW(div_fixup) SHOW(bpermute)
+    return 0;
+}

@@ -210,7 +210,7 @@ int main(int argc, char ** argv)
     }
     unsigned long long verified = 0, mismatches = 0;
 
-    const double C_NODE = 57, C_LEAF = 160, C_DONE = 150;        // wave instructions per step (from the ISA)
+    const double C_NODE = 56, C_LEAF = 125, C_DONE = 115;   // incl. ~6 for the vote        // wave instructions per step (from the ISA)
     for (int p = 0; p < (verify ? 1 : 14); ++p) {
         Sim s = base;
         s.pol.stack_dist = 0; s.pol.sorted_push = 0; s.pol.postpone = 0;
