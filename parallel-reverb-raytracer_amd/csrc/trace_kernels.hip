@@ -6,9 +6,9 @@
 //                  are 6250 waves instead of 1563 and the chip has enough waves to hide the
 //                  dependent node fetches.  Per bounce it leaves a 64-byte work record in the
 //                  ray's Impulse slot.
-//   image_kernel   one lane per (ray, bounce < 9): image-source validation (kernel.cpp:379-457).
-//                  The reference does this inside the ray's loop; its inputs are only the
-//                  triangles the ray hit so far, so it parallelises 9x wider here.
+//   image_kernel   one lane per ray: image-source validation of its first nine bounces (kernel.cpp:379-457),
+//                  the chain of mirrored triangles grown bounce by bounce.  Its inputs are only the triangles
+//                  the ray hit, so it runs beside the record grouping instead of inside the ray's loop.
 //   shadow_kernel  four lanes per (ray, bounce): the diffuse shadow ray to the microphone and the
 //                  final Impulse (kernel.cpp:463-490).  nrays*nreflections independent any-hit
 //                  queries: this is where the chip fills up.
@@ -680,15 +680,37 @@ __device__ __forceinline__ bool point_visible_lane(const SceneDev & sc, v3 begin
     return !traverse_lane<true>(sc, begin, normalize3(b2p), mag, stack, h);
 }
 
+// A mirror plane of the image-source chain: the unit normal of a (mirrored) triangle and its first vertex.
+// mirror_point (rvb_math.h, kernel.cpp:216-221) recomputes that normal — a cross product, a square root and three divisions —
+// for every point it mirrors; here it is computed ONCE per plane with the same operations on the same operands, so the
+// mirrored points are bit-identical.
+struct MirrorPlane { v3 n, v0; };
+__device__ __forceinline__ MirrorPlane mirror_plane(const TriVerts & t)
+{
+    MirrorPlane m;
+    m.n = verts_normal(t);
+    m.v0 = t.v0;
+    return m;
+}
+__device__ __forceinline__ void mirror_point_on(v3 & p, const MirrorPlane & m)
+{
+    const float d = dot3(m.n, p - m.v0);
+    p = p + ((-m.n) * d) * 2.0f;
+}
+
+// One lane per RAY, walking its first nine bounces in order (as the reference's work-item does, kernel.cpp:379-457): the
+// mirrored triangle of bounce k is the hit triangle mirrored through the k planes before it, which are the same for every
+// later bounce of the ray — so the chain grows by one triangle per bounce instead of being rebuilt per (ray, bounce) pair
+// (45 triangle mirrorings per ray instead of 165, and a tenth of the mirror-plane normals).
 __global__ __launch_bounds__(WAVE) void image_kernel(TraceArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t stack_lds[];   // [stack_entries][WAVE]
     const uint32_t lane = threadIdx.x;
     uint32_t * stack = stack_lds + lane;
-    const uint64_t g = (uint64_t) blockIdx.x * WAVE + lane;
+    const uint64_t ray = (uint64_t) blockIdx.x * WAVE + lane;
     const v3 mic = ld3(a.mic), source = ld3(a.source);
 
-    if (g == 0) {
+    if (ray == 0) {
         // slot 0, the direct path (kernel.cpp:335-357): identical for every ray, computed once
         rvb_impulse direct;
         for (int b = 0; b < 8; ++b) direct.volume[b] = 0.0f;
@@ -701,76 +723,77 @@ __global__ __launch_bounds__(WAVE) void image_kernel(TraceArgs a)
         }
         *a.direct = direct;
     }
+    if (ray >= a.nrays)
+        return;
 
     const uint32_t per_ray = RVB_NUM_IMAGE_SOURCE - 1;
-    if (g >= a.nrays * per_ray)
-        return;
-    const uint64_t ray = g / per_ray;
-    const uint32_t index = (uint32_t) (g % per_ray);
-    if (index >= a.nreflections)
-        return;
     const uint32_t * early = a.early + ray * per_ray;
-    const uint32_t tri_here = early[index];
-    if (tri_here == NONE)
-        return;                                   // the ray escaped before this bounce
-
-    // kernel.cpp:381-394: mirror the triangle chain and the microphone
+    const uint32_t last = a.nreflections < per_ray ? a.nreflections : per_ray;
     TriVerts prev[RVB_NUM_IMAGE_SOURCE - 1];
+    MirrorPlane plane[RVB_NUM_IMAGE_SOURCE - 1];
     v3 mic_reflection = mic;
-    for (uint32_t k = 0; k <= index; ++k) {
-        TriVerts current = load_corners(a.scene, early[k]);
-        for (uint32_t j = 0; j < k; ++j)
-            mirror_verts(current, prev[j]);
-        prev[k] = current;
-        mirror_point(mic_reflection, current);
-    }
-
-    // kernel.cpp:396-429
-    const v3 dir = normalize3(mic_reflection - source);
-    bool intersects = true;
-    v3 prev_intersection = source;
-    for (uint32_t k = 0; k != index + 1 && intersects; ++k) {
-        const float to_intersection = mt_intersect_verts(prev[k], source, dir);
-        if (to_intersection <= RVB_EPSILON) {
-            intersects = false;
-            break;
+    for (uint32_t index = 0; index < last; ++index) {
+        const uint32_t tri_here = early[index];
+        if (tri_here == NONE)
+            break;                                // the ray escaped before this bounce
+        // kernel.cpp:381-394: this bounce's triangle through the planes so far, then the microphone through it
+        TriVerts current = load_corners(a.scene, tri_here);
+        for (uint32_t j = 0; j < index; ++j) {
+            mirror_point_on(current.v0, plane[j]);
+            mirror_point_on(current.v1, plane[j]);
+            mirror_point_on(current.v2, plane[j]);
         }
-        v3 ip = source + dir * to_intersection;
-        for (int l = (int) k - 1; l != -1; --l)
-            mirror_point(ip, prev[l]);
+        prev[index] = current;
+        plane[index] = mirror_plane(current);
+        mirror_point_on(mic_reflection, plane[index]);
 
-        const v3 idir = normalize3(ip - prev_intersection);
-        Hit h;
-        const bool found = traverse_lane<false>(a.scene, prev_intersection, idir, 0.0f, stack, h);
-        const float hd = found ? h.t : 0.0f;                          // Intersection {0, 0, false}
-        const v3 nip = prev_intersection + idir * hd;
-        const bool lo = (nip.x - RVB_EPSILON < ip.x) && (nip.y - RVB_EPSILON < ip.y) && (nip.z - RVB_EPSILON < ip.z);
-        const bool hi = (ip.x < nip.x + RVB_EPSILON) && (ip.y < nip.y + RVB_EPSILON) && (ip.z < nip.z + RVB_EPSILON);
-        intersects = found && lo && hi;
-        prev_intersection = ip;
-    }
-    if (intersects)
-        intersects = point_visible_lane(a.scene, prev_intersection, mic, stack);   // kernel.cpp:431-440
-    if (!intersects)
-        return;
+        // kernel.cpp:396-429
+        const v3 dir = normalize3(mic_reflection - source);
+        bool intersects = true;
+        v3 prev_intersection = source;
+        for (uint32_t k = 0; k != index + 1 && intersects; ++k) {
+            const float to_intersection = mt_intersect_verts(prev[k], source, dir);
+            if (to_intersection <= RVB_EPSILON) {
+                intersects = false;
+                break;
+            }
+            v3 ip = source + dir * to_intersection;
+            for (int l = (int) k - 1; l != -1; --l)
+                mirror_point_on(ip, plane[l]);
 
-    // kernel.cpp:442-456: the ray's volume BEFORE this bounce's surface is applied
-    float volume[8];
-    if (index == 0) {
-        for (int b = 0; b < 8; ++b) volume[b] = 1.0f;
-    } else {
-        const float4 * rec = reinterpret_cast<const float4 *>(a.impulses + ray * a.nreflections + (index - 1));
-        const float4 v0 = rec[0], v1 = rec[1];
-        volume[0] = v0.x; volume[1] = v0.y; volume[2] = v0.z; volume[3] = v0.w;
-        volume[4] = v1.x; volume[5] = v1.y; volume[6] = v1.z; volume[7] = v1.w;
+            const v3 idir = normalize3(ip - prev_intersection);
+            Hit h;
+            const bool found = traverse_lane<false>(a.scene, prev_intersection, idir, 0.0f, stack, h);
+            const float hd = found ? h.t : 0.0f;                          // Intersection {0, 0, false}
+            const v3 nip = prev_intersection + idir * hd;
+            const bool lo = (nip.x - RVB_EPSILON < ip.x) && (nip.y - RVB_EPSILON < ip.y) && (nip.z - RVB_EPSILON < ip.z);
+            const bool hi = (ip.x < nip.x + RVB_EPSILON) && (ip.y < nip.y + RVB_EPSILON) && (ip.z < nip.z + RVB_EPSILON);
+            intersects = found && lo && hi;
+            prev_intersection = ip;
+        }
+        if (intersects)
+            intersects = point_visible_lane(a.scene, prev_intersection, mic, stack);   // kernel.cpp:431-440
+        if (!intersects)
+            continue;
+
+        // kernel.cpp:442-456: the ray's volume BEFORE this bounce's surface is applied
+        float volume[8];
+        if (index == 0) {
+            for (int b = 0; b < 8; ++b) volume[b] = 1.0f;
+        } else {
+            const float4 * rec = reinterpret_cast<const float4 *>(a.impulses + ray * a.nreflections + (index - 1));
+            const float4 v0 = rec[0], v1 = rec[1];
+            volume[0] = v0.x; volume[1] = v0.y; volume[2] = v0.z; volume[3] = v0.w;
+            volume[4] = v1.x; volume[5] = v1.y; volume[6] = v1.z; volume[7] = v1.w;
+        }
+        rvb_image_candidate cand;
+        cand.ray = a.ray_offset + ray;
+        cand.slot = index + 1;
+        cand.index = tri_here + 1;
+        make_image(a, mic, mic_reflection, source, volume, cand.impulse);
+        const uint32_t at = atomicAdd(a.candidate_count, 1u);
+        a.candidates[at] = cand;
     }
-    rvb_image_candidate cand;
-    cand.ray = a.ray_offset + ray;
-    cand.slot = index + 1;
-    cand.index = tri_here + 1;
-    make_image(a, mic, mic_reflection, source, volume, cand.impulse);
-    const uint32_t at = atomicAdd(a.candidate_count, 1u);
-    a.candidates[at] = cand;
 }
 
 // The shadow rays as Jobs: a quad walks the work records g, g + stride, ...; next() loads a record
@@ -929,8 +952,7 @@ void rvb_launch_path(const TraceArgs & a, hipStream_t s)
 
 void rvb_launch_images(const TraceArgs & a, hipStream_t s)
 {
-    const uint64_t work = a.nrays * (RVB_NUM_IMAGE_SOURCE - 1);
-    const unsigned blocks = (unsigned) ((work + WAVE - 1) / WAVE);
+    const unsigned blocks = (unsigned) ((a.nrays + WAVE - 1) / WAVE);     // one lane per ray
     hipLaunchKernelGGL(image_kernel, dim3(blocks ? blocks : 1), dim3(WAVE), a.stack_entries * WAVE * sizeof(uint32_t), s, a);
 }
 
