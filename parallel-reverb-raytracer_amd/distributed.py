@@ -215,3 +215,22 @@ class IrPipeline:
             if on_result:
                 on_result(hist, info, self.tracers[slot])
         self.next_slot = (first + len(jobs)) % n
+
+
+def generate_pair_irs(tracers, pairs, nreflections, air, model_for_pair, sample_rate, rank=0, world=1, device="cpu",
+                      trim_predelay=True, mode=capi.IR_FAST, which=capi.IR_ALL, remove_direct=False):
+    """BASELINE config C5: many (source, listener) pairs in one scene.  The PAIRS shard over the ranks (contiguous blocks,
+    shard_range) and every rank traces its own pairs with all of its rays — no collective at all; on a
+    rank the pairs run as jobs of the two-context pipeline.  `pairs` = [(mic, source)], `model_for_pair(i)` -> SpeakerModel /
+    HrtfModel of pair i; `tracers` = this rank's contexts (same scene and rays on each).  Returns {pair index: (hist, info)}
+    for this rank's pairs."""
+    first, count = shard_range(len(pairs), rank, world)
+    jobs, out = [], {}
+    for i in range(first, first + count):
+        mic, source = pairs[i]
+        jobs.append(((mic, source, nreflections, air),
+                     dict(model=model_for_pair(i), sample_rate=sample_rate, trim_predelay=trim_predelay, mode=mode, device=device,
+                          which=which, remove_direct=remove_direct)))        # rank 0 / world 1 inside generate_ir: a pair is not sharded
+    order = list(range(first, first + count))
+    IrPipeline(tracers).run_jobs(jobs, lambda hist, info, _tracer: out.__setitem__(order[len(out)], (hist, info)))
+    return out

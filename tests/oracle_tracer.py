@@ -40,6 +40,16 @@ class OracleTracer:
         self.channels = [self.oracle.attenuate_speaker(mic, self.impulses, d, c) for d, c in zip(directions, coefficients)]
         self.nchannels = len(self.channels)
 
+    def ir_configure_hrtf(self, mic, table, facing, up, which=capi.IR_ALL, images=None):
+        parts = []
+        if which & capi.IR_DIFFUSE:
+            parts.append(self.diffuse)
+        if (which & capi.IR_IMAGES) and images is not None:
+            parts.append(np.ascontiguousarray(images, dtype=IMPULSE))
+        self.impulses = np.concatenate(parts) if parts else np.zeros(0, IMPULSE)
+        self.channels = [self.oracle.attenuate_hrtf(mic, self.impulses, table[ch], facing, up, ch) for ch in (0, 1)]
+        self.nchannels = 2
+
     def ir_time_range(self):
         t = np.concatenate([c["time"] for c in self.channels]) if self.channels else np.zeros(0, np.float32)
         nz = t[t != 0]

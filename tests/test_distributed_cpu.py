@@ -144,3 +144,50 @@ def test_ir_pipeline_alternates_contexts_and_changes_nothing(tmp_path, oracle):
     assert all(np.array_equal(h, two[0]["hists"][0]) for h in two[0]["hists"])
     a, b = plain.astype(np.float64), two[0]["hists"][0].astype(np.float64)
     assert (np.abs(a - b) <= 1e-5 * (np.abs(a).max(axis=2, keepdims=True) + 1e-30)).all()
+
+
+def _pairs_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import rvb_import
+    rvb_import.load()
+    import torch.distributed as dist
+    import pyoracle
+    from oracle_tracer import OracleTracer
+    from parallel_reverb_raytracer_amd import capi, distributed, dtypes, scenes
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    scene, _ = scenes.concert_hall(900)
+    src, mic = scenes.source_mic_pairs(5, seed=2)
+    table = scenes.hrtf_synthetic_table()
+    dirs = scenes.sphere_directions(40, seed=4)
+    tracers = [OracleTracer(pyoracle.Oracle("port"), scene, dirs) for _ in range(2)]
+
+    def model(i):
+        facing = src[i] - mic[i]
+        return distributed.HrtfModel(table, facing / np.linalg.norm(facing), (0, 1, 0))
+
+    got = distributed.generate_pair_irs(tracers, [(mic[i], src[i]) for i in range(5)], 6, dtypes.AIR_COEFFICIENTS, model, 44100.0,
+                                        rank=rank, world=world, mode=capi.IR_EXACT)
+    np.savez(os.path.join(out_dir, "pairs_rank%d_of%d.npz" % (rank, world)), index=np.array(sorted(got)),
+             **{"hist%d" % i: got[i][0].numpy() for i in got})
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_source_listener_pairs_shard_over_ranks_without_a_collective(tmp_path, oracle):
+    """Config C5's decomposition: 5 pairs on 2 ranks (3 + 2), HRTF model, every pair's IR equal to the single-process one."""
+    import torch.multiprocessing as mp
+    _pairs_worker(0, 1, 0, str(tmp_path))
+    mp.spawn(_pairs_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    one = np.load(os.path.join(str(tmp_path), "pairs_rank0_of1.npz"))
+    two = [np.load(os.path.join(str(tmp_path), "pairs_rank%d_of2.npz" % r)) for r in (0, 1)]
+    assert list(one["index"]) == [0, 1, 2, 3, 4]
+    assert list(two[0]["index"]) == [0, 1, 2] and list(two[1]["index"]) == [3, 4]
+    for r in (0, 1):
+        for i in two[r]["index"]:
+            assert np.array_equal(two[r]["hist%d" % i], one["hist%d" % i])
+    assert any(one["hist%d" % i].any() for i in range(5))
