@@ -29,7 +29,7 @@ from parallel_reverb_raytracer_amd import capi, distributed, dtypes, scenes  # n
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 4   # 256 CUs x 4 SIMDs, one VALU wave-instruction per 4 cycles at 2.4 GHz = 614.4 G/s
-PMC_FILE = "r01c_pmc_n1.json"
+PMC_FILE = "r01d_pmc_n1.json"
 
 
 def parse():
@@ -143,10 +143,12 @@ def main():
     for c in contexts:
         distributed.generate_ir(c, *trace_args, **ir_kwargs(None))
     fence()
+    solo_irs = 4
     t0 = time.perf_counter()
-    distributed.generate_ir(ctx, *trace_args, **ir_kwargs(solo_ms))
-    ctx.synchronize()
-    solo_latency_ms = (time.perf_counter() - t0) * 1e3
+    for _ in range(solo_irs):
+        distributed.generate_ir(ctx, *trace_args, **ir_kwargs(solo_ms))
+        ctx.synchronize()
+    solo_latency_ms = (time.perf_counter() - t0) * 1e3 / solo_irs
     pipeline.run(args.warmup, trace_args, ir_kwargs(None), keep)
     fence()
     t0 = time.perf_counter()
