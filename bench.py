@@ -46,6 +46,8 @@ def parse():
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     p.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
+    p.add_argument("--rehearse-collectives", action="store_true",
+                   help="with one rank: create the process group anyway and run every collective of the multi-GPU path on it")
     p.add_argument("--contexts", type=int, default=2, help="contexts per GPU that alternate IRs (2: the trace of IR i+1 runs beside the "
                    "grouping / binning / host stages of IR i; 1: strictly one IR at a time)")
     return p.parse_args()
@@ -76,6 +78,12 @@ def cpu_baseline(scene, mic, src, nrefl, target_seconds):
 
 def main():
     args = parse()
+    # Rank 0 owes the driver ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner to
+    # stdout when a communicator is created, gloo its connection notes), so everything that is not the result goes to stderr:
+    # file descriptor 1 is pointed at stderr for the whole run and the JSON line is written to the saved original.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -83,8 +91,12 @@ def main():
     import torch.distributed as dist
     if args.share_gpu:
         local_rank = 0
-    if world > 1:
+    grouped = world > 1 or args.rehearse_collectives
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -125,7 +137,7 @@ def main():
                 for k, v in tracer.last_timings():
                     sink.setdefault(k, []).append(v)
         return dict(speakers_dir=speakers_dir, speakers_coeff=speakers_coeff, sample_rate=sr, trim_predelay=True, mode=mode,
-                    rank=rank, world=world, ray_offset=rank * nrays, device=device, on_stage=on_stage)
+                    rank=rank, world=world, ray_offset=rank * nrays, device=device, on_stage=on_stage, collectives=grouped)
 
     def keep(hist, info, _tracer):
         state.update(hist=hist, nbins=info["nbins"], images=info["images"], predelay=info["predelay"])
@@ -134,7 +146,7 @@ def main():
         for c in contexts:
             c.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -155,7 +167,7 @@ def main():
     pipeline.run(args.steps, trace_args, ir_kwargs(kernel_ms), keep)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if grouped:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
@@ -260,8 +272,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(scene, mic, src, nrefl, args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
-    if world > 1:
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if grouped:
         dist.destroy_process_group()
 
 

@@ -106,7 +106,7 @@ def begin_ir(tracer, mic, source, nreflections, air, ray_offset=0):
 
 def generate_ir(tracer, mic, source, nreflections, air, speakers_dir=None, speakers_coeff=None, sample_rate=44100.0,
                 trim_predelay=True, mode=capi.IR_FAST, rank=0, world=1, ray_offset=0, device="cpu",
-                which=capi.IR_ALL, remove_direct=False, on_stage=None, begun=False, model=None):
+                which=capi.IR_ALL, remove_direct=False, on_stage=None, begun=False, model=None, collectives=None):
     """One impulse response from the rays already set on `tracer`.  Returns (hist tensor
     [nchannels][8][nbins] — identical on every rank —, info dict).
 
@@ -123,6 +123,8 @@ def generate_ir(tracer, mic, source, nreflections, air, speakers_dir=None, speak
     import torch.distributed as dist
 
     empty = np.zeros(0, dtype=IMPULSE)
+    if collectives is None:                              # True with world == 1 rehearses the multi-rank code path on one rank
+        collectives = world > 1
     if model is None:                                    # the two-list form: speakers (what bench.py and the reference demo configs use)
         model = SpeakerModel(speakers_dir, speakers_coeff)
     if not begun:
@@ -132,7 +134,7 @@ def generate_ir(tracer, mic, source, nreflections, air, speakers_dir=None, speak
         on_stage("trace", tracer)
     direct = tracer.get_direct()
     want_images = bool(which & capi.IR_IMAGES)
-    if world == 1:
+    if not collectives:
         images = capi.merge_images(candidates, direct, remove_direct) if want_images else empty
         model.configure(tracer, mic, which, images)
         lo, hi = tracer.ir_time_range()
@@ -168,7 +170,7 @@ def generate_ir(tracer, mic, source, nreflections, air, speakers_dir=None, speak
     if on_stage:
         on_stage("accumulate", tracer)
     tracer.synchronize()
-    if world > 1:
+    if collectives:
         dist.all_reduce(hist, op=dist.ReduceOp.SUM)      # RCCL over xGMI: [channels][8][nbins] floats
     return hist, {"nbins": nbins, "predelay": predelay, "images": int(images.shape[0]), "max_time": hi}
 
