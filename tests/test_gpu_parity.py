@@ -149,6 +149,60 @@ def test_many_surfaces_take_the_global_memory_path(ctx, oracle):
     assert_impulses_equal(ctx.get_raw_images(False), oracle.collect_images(image, index, False), "300 surfaces images")
 
 
+def triangle_soup(seed):
+    """An open scene made to stress the acceleration structure's bookkeeping: random triangles of every size, exact duplicates
+    (equal distances: the lowest index must win, kernel.cpp:180-188), coplanar overlapping pairs, zero-area and millimetre
+    triangles (never hittable: |det| < 1e-4, quirk Q7), and vertices that are NaN or infinite."""
+    from parallel_reverb_raytracer_amd.dtypes import SURFACE, TRIANGLE, aligned_zeros, float3_array
+    rng = np.random.default_rng(seed)
+    verts, tris = [], []
+
+    def add(p0, p1, p2):
+        base = len(verts)
+        verts.extend([p0, p1, p2])
+        tris.append((int(rng.integers(0, 3)), base, base + 1, base + 2))
+
+    for _ in range(500):                                              # ordinary triangles, 5 cm .. 4 m
+        c = rng.uniform(-6, 6, 3)
+        size = 10.0 ** rng.uniform(-1.3, 0.6)
+        add(c + rng.normal(size=3) * size, c + rng.normal(size=3) * size, c + rng.normal(size=3) * size)
+    for k in rng.integers(0, 500, 40):                                # exact duplicates of earlier triangles (new vertex copies)
+        _, a, b, c3 = tris[k]
+        add(np.array(verts[a]), np.array(verts[b]), np.array(verts[c3]))
+    for _ in range(30):                                               # coplanar overlapping pairs
+        c = rng.uniform(-5, 5, 3)
+        u, v = rng.normal(size=3), rng.normal(size=3)
+        add(c, c + u, c + v)
+        add(c + 0.25 * u, c + 1.25 * u, c + 0.25 * u + v)
+    for _ in range(20):                                               # zero area and millimetre size
+        c = rng.uniform(-5, 5, 3)
+        add(c, c, c + rng.normal(size=3))
+        add(c, c + rng.normal(size=3) * 1e-3, c + rng.normal(size=3) * 1e-3)
+    for bad in (np.nan, np.inf, -np.inf):                             # not finite
+        c = rng.uniform(-5, 5, 3)
+        add(c, c + 1.0, np.array([bad, 0.0, 1.0]))
+    t = aligned_zeros(len(tris), TRIANGLE)
+    arr = np.asarray(tris, dtype=np.uint64)
+    t["surface"], t["v0"], t["v1"], t["v2"] = arr[:, 0], arr[:, 1], arr[:, 2], arr[:, 3]
+    surfaces = aligned_zeros(3, SURFACE)
+    surfaces["specular"] = rng.uniform(0.6, 0.99, (3, 8)).astype(np.float32)
+    surfaces["diffuse"] = rng.uniform(0.4, 0.9, (3, 8)).astype(np.float32)
+    return t, float3_array(np.asarray(verts, dtype=np.float64)), surfaces
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_triangle_soup_matches_brute_force(ctx, oracle, seed):
+    scene = triangle_soup(seed)
+    mic, src = (0.3, -0.2, 0.1), (-0.5, 0.4, 0.2)
+    dirs = scenes.sphere_directions(3000, seed=40 + seed)
+    ctx.set_scene(scene)
+    ctx.raytrace(mic, src, dirs, 7, AIR_COEFFICIENTS)
+    want, image, index = oracle.raytrace(scene, mic, src, dirs, 7, AIR_COEFFICIENTS)
+    assert_impulses_equal(ctx.get_raw_diffuse(), want, "soup %d" % seed)
+    assert_impulses_equal(ctx.get_raw_images(False), oracle.collect_images(image, index, False), "soup %d images" % seed)
+    assert np.count_nonzero(want["time"]) > 100                       # the case is not vacuous: rays do hit and see the microphone
+
+
 def test_edge_cases_empty_and_ragged(ctx, oracle):
     scene = scenes.rotated_square_room(n=1)
     ctx.set_scene(scene)
