@@ -206,11 +206,21 @@ class IrPipeline:
             begin_ir(self.tracers[slot], *trace_args, ray_offset=ir_kwargs.get("ray_offset", 0))
             self.begun[slot] = True
 
-        begin(0)
+        # Jobs are enqueued in GROUPS of `group` traces (their path kernels then run side by side: more waves per SIMD, see
+        # DESIGN.md "rays per launch"), and group j+1 is enqueued before group j is finished.  group = len(tracers) // 2;
+        # two contexts: group 1 = the plain alternation.
+        group = max(1, n // 2) if n > 1 else 1
+        group = min(group, int(__import__("os").environ.get("RVB_PIPELINE_GROUP", group)))       # (an override may only shrink it)
+
+        def begin_group(j):
+            for k in range(j * group, min((j + 1) * group, len(jobs))):
+                begin(k)
+
+        begin_group(0)
         for i, (trace_args, ir_kwargs) in enumerate(jobs):
             slot = (first + i) % n
-            if i + 1 < len(jobs) and n > 1:
-                begin(i + 1)
+            if n > 1 and i % group == 0:
+                begin_group(i // group + 1)
             began = self.begun[slot]
             self.begun[slot] = False
             hist, info = generate_ir(self.tracers[slot], *trace_args, begun=began, **ir_kwargs)
