@@ -139,6 +139,17 @@ struct Sim {
         for (int i = 0; i < m; ++i) { q.stack.push_back(n.c[order[i]].ref); q.stack_t.push_back(tn[order[i]]); ++pushes; }
         q.ref = n.c[winner].ref;
     }
+    // the triangle tests of one leaf, no stack movement
+    void leaf_test(Query & q, uint32_t ref)
+    {
+        ++leaf_steps;
+        const uint32_t first = ref & 0x0FFFFFFFu, count = ((ref >> 28) & 7u) + 1u;
+        for (uint32_t j = 0; j < count; ++j) {
+            const BvhTri & t = bs.tris[first + j];
+            float dist = mt_intersect(mk3(t.v0[0], t.v0[1], t.v0[2]), mk3(t.e0[0], t.e0[1], t.e0[2]), mk3(t.e1[0], t.e1[1], t.e1[2]), q.o, q.d);
+            if (dist > RVB_EPSILON && (q.best_i == 0xFFFFFFFFu || dist < q.best_t || (dist == q.best_t && t.index < q.best_i))) { q.best_t = dist; q.best_i = t.index; }
+        }
+    }
     // one leaf step; returns true when the query has finished
     bool leaf_step(Query & q)
     {
@@ -229,7 +240,18 @@ int main(int argc, char ** argv)
                 s.begin(q[i], r[i].o, r[i].d, false, 0.0f);
                 st[i] = NODE;
             }
+            const int hold = getenv("TRAVSIM_POSTPONE") ? atoi(getenv("TRAVSIM_POSTPONE")) : 0;   // leaves a quad may hold back (vote only)
             auto classify = [&](int i) {
+                if (hold && sched == 1) {
+                    // a quad that reaches a leaf holds it back and keeps walking while it may; leaves are tested when voted
+                    while (q[i].ref != 0xFFFFFFFFu && (q[i].ref & RVB_BVH_LEAF) && (int) q[i].held.size() < hold && !q[i].stack.empty()) {
+                        q[i].held.push_back(q[i].ref);
+                        s.pop(q[i]);
+                    }
+                    if (q[i].ref == 0xFFFFFFFFu) st[i] = q[i].held.empty() ? DONE : LEAF;
+                    else st[i] = (q[i].ref & RVB_BVH_LEAF) ? LEAF : NODE;
+                    return;
+                }
                 if (q[i].ref == 0xFFFFFFFFu) st[i] = DONE;
                 else st[i] = (q[i].ref & RVB_BVH_LEAF) ? LEAF : NODE;
             };
@@ -266,7 +288,16 @@ int main(int argc, char ** argv)
                     for (int i = 0; i < nq; ++i) if (st[i] == NODE) { s.node_step(q[i]); classify(i); if (q[i].stack.size() > maxstack) maxstack = q[i].stack.size(); }
                 } else if (act == LEAF) {
                     ++w_leaf; q_leaf_active += cl;
-                    for (int i = 0; i < nq; ++i) if (st[i] == LEAF) { bool f = s.leaf_step(q[i]); if (f) st[i] = DONE; else classify(i); }
+                    for (int i = 0; i < nq; ++i) if (st[i] == LEAF) {
+                        if (hold && sched == 1) {
+                            // one leaf per step: a held one first, else the current one (then move on)
+                            if (!q[i].held.empty()) { s.leaf_test(q[i], q[i].held.back()); q[i].held.pop_back(); }
+                            else { s.leaf_test(q[i], q[i].ref); s.pop(q[i]); }
+                            classify(i);
+                            continue;
+                        }
+                        bool f = s.leaf_step(q[i]); if (f) st[i] = DONE; else classify(i);
+                    }
                 } else {
                     ++w_done; q_done_active += cd;
                     for (int i = 0; i < nq; ++i) if (st[i] == DONE) {
