@@ -368,9 +368,13 @@ __global__ __launch_bounds__(256) void bin_keys_kernel(ModelDev m, uint32_t ch, 
         const float time = r[3].x;
         const bool nonzero = v0.x != 0.0f || v0.y != 0.0f || v0.z != 0.0f || v0.w != 0.0f
                           || v1.x != 0.0f || v1.y != 0.0f || v1.z != 0.0f || v1.w != 0.0f;
-        float t = 0.0f;                       // {0, 0} for zero-volume impulses (quirk Q2) -> bin 0
-        if (nonzero) t = attenuated_time(m, ch, mk3(p.x, p.y, p.z), time);
-        keys[index_base + i] = time_bin(t, predelay, sample_rate);
+        // A zero-volume impulse attenuates to {0, 0} (quirk Q2): the reference adds its zeros to bin 0, which changes nothing
+        // (x + 0 = x, and a sum that starts at +0 never becomes -0).  It gets the key 0xFFFFFFFF — sorted last, matched by no
+        // bin — instead of bin 0: the blocked third of all shadow rays would otherwise make ONE lane of ordered_sum_kernel walk
+        // millions of entries (2.2 s at workload C2).
+        uint32_t key = 0xFFFFFFFFu;
+        if (nonzero) key = time_bin(attenuated_time(m, ch, mk3(p.x, p.y, p.z), time), predelay, sample_rate);
+        keys[index_base + i] = key;
         values[index_base + i] = (uint32_t) (index_base + i);
     }
 }
@@ -425,9 +429,15 @@ __global__ __launch_bounds__(256) void flat_keys_kernel(const rvb_attenuated_imp
 {
     float tmax = 0.0f;
     for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
-        const float t = in[i].time;
-        tmax = fmaxf(tmax, t);
-        keys[i] = (uint32_t) roundf(t * sample_rate);
+        const float4 * r = reinterpret_cast<const float4 *>(in + i);
+        const float4 v0 = r[0], v1 = r[1];
+        const float t = r[2].x;
+        tmax = fmaxf(tmax, t);                 // MAX_SAMPLE counts every impulse (rayverb.cpp:54-57)
+        // an all-zero volume adds nothing to its bin (x + 0 = x): keyed past every bin, so that the many {0, 0} entries of an
+        // attenuated array (quirk Q2) do not pile up on the one lane that owns bin 0
+        const bool nonzero = v0.x != 0.0f || v0.y != 0.0f || v0.z != 0.0f || v0.w != 0.0f
+                          || v1.x != 0.0f || v1.y != 0.0f || v1.z != 0.0f || v1.w != 0.0f;
+        keys[i] = nonzero ? (uint32_t) roundf(t * sample_rate) : 0xFFFFFFFFu;
         values[i] = (uint32_t) i;
     }
     for (int off = 32; off > 0; off >>= 1)
