@@ -375,6 +375,7 @@ int rvb_trace(rvb_ctx * ctx, const float mic[3], const float source[3], uint64_t
     a.nreflections = (uint32_t) nreflections;
     a.stack_entries = ctx->stack_need;
     a.lds_surfaces = rvb_lds_surfaces(ctx->stack_need, ctx->nsurfaces);
+    a.scene_nodes = (uint32_t) ctx->nnodes;
     a.ray_offset = ray_offset;
     for (int i = 0; i < 3; ++i) { a.mic[i] = mic[i]; a.source[i] = source[i]; ctx->mic[i] = mic[i]; }
     for (int i = 0; i < 8; ++i) a.air[i] = air_coefficient[i];

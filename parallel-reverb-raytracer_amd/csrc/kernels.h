@@ -36,6 +36,7 @@ struct TraceArgs {
     uint32_t nreflections;
     uint32_t stack_entries;             // LDS traversal stack entries per lane (BuiltScene::stack_need)
     uint32_t lds_surfaces;              // surfaces staged in LDS behind the stack by the quad kernels (rvb_lds_surfaces), 0 = none
+    uint32_t scene_nodes;               // number of BVH nodes (experiments that stage the top of the tree)
     uint64_t ray_offset;
     float mic[3];
     float source[3];

@@ -31,6 +31,9 @@
 #ifndef RVB_SHADOW_JOBS
 #define RVB_SHADOW_JOBS 0
 #endif
+#ifndef RVB_LDS_NODES
+#define RVB_LDS_NODES 0        // experiment: top nodes of the BVH staged in LDS per workgroup (path_kernel); 21 = levels 0-2
+#endif
 
 #define WAVE 64
 #define QUADS_PER_BLOCK 16          // rays (or records) per 64-lane workgroup in the quad kernels
@@ -63,6 +66,7 @@ struct Hit { float t; uint32_t tri; };
 #define RVB_STREAM_STORE 0
 #endif
 typedef float nt_float4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const nt_float4 * lds_float4_ptr;  // keeps ds_read: a generic pointer would load flat
 __device__ __forceinline__ void store_stream(float4 * p, const float4 v)
 {
     nt_float4 t = {v.x, v.y, v.z, v.w};
@@ -331,7 +335,8 @@ __device__ __forceinline__ int scalar_popcount(unsigned long long mask)
 // steps per bounce 37 -> 28, quads active per node step 6.7 -> 8.9, wave instructions per bounce -13 % before the
 // vote's own cost: three compares into SGPR masks and scalar popcounts per iteration.
 template <class Job>
-__device__ __forceinline__ void traverse_jobs_vote(const SceneDev & sc, uint32_t * __restrict__ stack, Job & job)
+__device__ __forceinline__ void traverse_jobs_vote(const SceneDev & sc, uint32_t * __restrict__ stack, Job & job,
+                                                   lds_float4_ptr lds_nodes = nullptr)
 {
     const uint32_t IDLE = 0xFFFFFFFEu;
     const uint32_t c = threadIdx.x & 3u;
@@ -363,7 +368,13 @@ __device__ __forceinline__ void traverse_jobs_vote(const SceneDev & sc, uint32_t
             break;
         if (n_node >= n_leaf && n_node >= n_done) {
             if ((int32_t) ref >= 0) {
+#if RVB_LDS_NODES
+                uint4 n;
+                if (ref < RVB_LDS_NODES * 64u) { const nt_float4 t = lds_nodes[(ref | child_off) >> 4]; n = make_uint4(__float_as_uint(t.x), __float_as_uint(t.y), __float_as_uint(t.z), __float_as_uint(t.w)); }
+                else n = *reinterpret_cast<const uint4 *>(node_base + (ref | child_off));
+#else
                 const uint4 n = *reinterpret_cast<const uint4 *>(node_base + (ref | child_off));
+#endif
                 const float limit = fmaf(__uint_as_float((uint32_t) (best_key >> 32)), cull_scale, sc.cull_abs);
                 float tn;
                 const bool ok = slab(n, ix, iy, iz, oix, oiy, oiz, limit, neg_cull, tn);
@@ -532,7 +543,6 @@ __device__ __forceinline__ v3 ld3(const float * p) { return mk3(p[0], p[1], p[2]
 // Copies the scene's surface table (64 B per surface) behind the traversal stack in LDS when the launch reserved
 // room for it (TraceArgs::lds_surfaces = number of surfaces staged, 0 = none).  Single-wave workgroups: the
 // barrier is only the wait for the wave's own LDS writes.
-typedef __attribute__((address_space(3))) const nt_float4 * lds_float4_ptr;  // keeps ds_read: a generic pointer would load flat
 __device__ __forceinline__ float4 lds_load4(lds_float4_ptr p, uint32_t i)
 {
     const nt_float4 t = p[i];
@@ -615,13 +625,29 @@ __global__ __launch_bounds__(WAVE, 8) void path_kernel(TraceArgs a)
     const uint32_t q = threadIdx.x >> 2;
     const uint64_t ray = (uint64_t) blockIdx.x * QUADS_PER_BLOCK + q;
     const lds_float4_ptr surf_lds = stage_surfaces(a, stack_lds + a.stack_entries * QUADS_PER_BLOCK);
+#if RVB_LDS_NODES
+    lds_float4_ptr lds_nodes;
+    {
+        uint4 * dst = reinterpret_cast<uint4 *>(stack_lds + a.stack_entries * QUADS_PER_BLOCK) + 4u * a.lds_surfaces;
+        const uint4 * src = reinterpret_cast<const uint4 *>(a.scene.nodes);
+        const uint32_t count = 4u * (RVB_LDS_NODES < a.scene_nodes ? RVB_LDS_NODES : a.scene_nodes);
+        for (uint32_t i = threadIdx.x; i < 4u * RVB_LDS_NODES; i += WAVE)
+            dst[i] = i < count ? src[i] : make_uint4(0x7E007E00u, 0x7E007E00u, 0x7E007E00u, RVB_BVH_EMPTY);
+        __syncthreads();
+        lds_nodes = (lds_float4_ptr) dst;
+    }
+#endif
     if (ray >= a.nrays)
         return;                                   // whole quads leave together
     const float4 d4 = a.directions[ray];
     PathJob<SURF_LDS> job = {a, (uint32_t) ray, threadIdx.x & 3u, ld3(a.source), mk3(d4.x, d4.y, d4.z), 0.0f,
                    make_float4(1.0f, 1.0f, 1.0f, 1.0f), 0u, true, surf_lds};
 #if RVB_PATH_JOBS == 2
+#if RVB_LDS_NODES
+    traverse_jobs_vote(a.scene, stack_lds + q, job, lds_nodes);
+#else
     traverse_jobs_vote(a.scene, stack_lds + q, job);
+#endif
 #elif RVB_PATH_JOBS
     traverse_jobs<false>(a.scene, stack_lds + q, job);
 #else
@@ -928,7 +954,7 @@ __global__ __launch_bounds__(WAVE, RVB_SHADOW_WAVES) void shadow_kernel(TraceArg
 // LDS of a quad kernel's single-wave workgroup: the traversal stack, then (optionally) the surface table
 static size_t quad_kernel_lds_bytes(const TraceArgs & a)
 {
-    return a.stack_entries * QUADS_PER_BLOCK * sizeof(uint32_t) + (size_t) a.lds_surfaces * sizeof(rvb_surface);
+    return a.stack_entries * QUADS_PER_BLOCK * sizeof(uint32_t) + (size_t) a.lds_surfaces * sizeof(rvb_surface) + RVB_LDS_NODES * 64u;
 }
 
 uint32_t rvb_lds_surfaces(uint32_t stack_entries, uint64_t nsurfaces)
