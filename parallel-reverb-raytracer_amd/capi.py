@@ -25,6 +25,7 @@ IR_FAST, IR_EXACT = 0, 1
 SYMBOLS = [
     "rvb_create", "rvb_destroy", "rvb_last_error", "rvb_synchronize", "rvb_wait_for_event", "rvb_device_info",
     "rvb_set_scene", "rvb_scene_info", "rvb_set_directions", "rvb_set_directions_device", "rvb_trace",
+    "rvb_trace_pairs", "rvb_ir_select_pair",
     "rvb_get_diffuse", "rvb_diffuse_device", "rvb_get_direct", "rvb_get_image_candidates", "rvb_merge_images",
     "rvb_attenuate_speaker", "rvb_attenuate_speaker_device", "rvb_attenuate_hrtf", "rvb_flatten",
     "rvb_ir_configure_speakers", "rvb_ir_configure_hrtf", "rvb_ir_time_range", "rvb_ir_bins", "rvb_ir_accumulate",
@@ -164,6 +165,27 @@ class Context:
     def trace(self, mic, source, nreflections, air, ray_offset=0):
         self._check(self.lib.rvb_trace(self.handle, _f3(mic), _f3(source), _u64(nreflections), _f8(air), _u64(ray_offset)))
         self.nreflections = int(nreflections)
+        self.npairs = 1
+
+    def trace_pairs(self, mics, sources, nreflections, air, ray_offset=0):
+        """Several (source, microphone) pairs in one launch (rvb_trace_pairs): [npairs][3] each; every pair uses the rays set on
+        this context.  Raw results are [npairs][nrays][nreflections]; select_pair(p) picks the pair the IR calls work on."""
+        m = np.ascontiguousarray(np.asarray(mics, dtype=np.float32).reshape(-1, 3))
+        s_ = np.ascontiguousarray(np.asarray(sources, dtype=np.float32).reshape(-1, 3))
+        assert m.shape == s_.shape and m.shape[0] >= 1
+        self._check(self.lib.rvb_trace_pairs(self.handle, _ptr(m), _ptr(s_), _u64(m.shape[0]), _u64(nreflections), _f8(air), _u64(ray_offset)))
+        self.nreflections = int(nreflections)
+        self.npairs = int(m.shape[0])
+
+    def select_pair(self, pair):
+        self._check(self.lib.rvb_ir_select_pair(self.handle, _u64(pair)))
+
+    def get_pair_candidates(self, pair, candidates=None):
+        """Image-source candidates of one pair of a trace_pairs launch, ray numbers relative to the pair."""
+        cand = self.get_image_candidates() if candidates is None else candidates
+        mine = cand[(cand["ray"] // np.uint64(self.nrays)) == np.uint64(pair)].copy()
+        mine["ray"] -= np.uint64(pair * self.nrays)
+        return mine
 
     def raytrace(self, mic, source, directions, nreflections, air):
         """Raytracer::raytrace (reference rayverb.cpp:538-685)."""
@@ -174,7 +196,7 @@ class Context:
         self._check(self.lib.rvb_synchronize(self.handle))
 
     def get_raw_diffuse(self):
-        out = np.zeros(self.nrays * self.nreflections, dtype=IMPULSE)
+        out = np.zeros(getattr(self, "npairs", 1) * self.nrays * self.nreflections, dtype=IMPULSE)
         self._check(self.lib.rvb_get_diffuse(self.handle, _ptr(out)))
         return out
 

@@ -63,6 +63,12 @@ struct rvb_ctx {
     bool traced = false;
     uint64_t nreflections = 0;
     float mic[3] = {0, 0, 0};
+    // last trace: npairs (source, microphone) pairs x nrays rays each; the IR stage works on one pair's slice at a time
+    uint64_t npairs = 1, traced_rays = 0, ir_pair = 0;
+    std::vector<float> pair_mics_host;          // [npairs][3]
+    DevBuf pair_geom, pair_direct, pair_range;   // device: mics+sources [2*npairs] float4, direct [npairs] Impulse, ranges [npairs][2]
+    std::vector<rvb_impulse> pair_direct_host;
+    std::vector<uint32_t> pair_range_host;
     DevBuf impulses, early, candidates, small, stamps, sort_keys, sort_scratch, sort_order, group_temp;       // small: [0] candidate count, [2..3] executed, [16..] direct, range
     unsigned char small_host[128] = {0};        // host mirror of `small`, fetched once per trace
     rvb_image_candidate first_candidates[32];   // ... together with the first few image-source candidates (usually all of them)
@@ -108,6 +114,12 @@ int fail(rvb_ctx * ctx, int code, const std::string & what)
 {
     if (ctx) ctx->error = what; else g_create_error = what;
     return code;
+}
+
+// the diffuse impulses the IR stage works on: the slice of the pair chosen with rvb_ir_select_pair (pair 0 of 1 otherwise)
+const rvb_impulse * ir_diffuse(const rvb_ctx * ctx)
+{
+    return ctx->impulses.as<rvb_impulse>() + ctx->ir_pair * ctx->nrays * ctx->nreflections;
 }
 
 #define RVB_HIP(ctx, call)                                                                              \
@@ -195,7 +207,8 @@ void rvb_destroy(rvb_ctx * ctx)
     if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
     for (DevBuf * b : {&ctx->nodes, &ctx->tris, &ctx->shade, &ctx->corners, &ctx->surfaces, &ctx->leafpos, &ctx->sort_keys, &ctx->sort_scratch, &ctx->sort_order, &ctx->group_temp, &ctx->directions_own, &ctx->impulses,
                        &ctx->early, &ctx->candidates, &ctx->small, &ctx->stamps, &ctx->images, &ctx->hrtf_table, &ctx->acc, &ctx->keys_a,
-                       &ctx->keys_b, &ctx->vals_a, &ctx->vals_b, &ctx->sort_temp, &ctx->scratch_in, &ctx->scratch_out, &ctx->hist})
+                       &ctx->keys_b, &ctx->vals_a, &ctx->vals_b, &ctx->sort_temp, &ctx->scratch_in, &ctx->scratch_out, &ctx->hist,
+                       &ctx->pair_geom, &ctx->pair_direct, &ctx->pair_range})
         b->release();
     for (hipEvent_t e : ctx->event_pool) (void) hipEventDestroy(e);
     if (ctx->path_done) (void) hipEventDestroy(ctx->path_done);
@@ -318,17 +331,16 @@ int rvb_set_directions_device(rvb_ctx * ctx, const void * d_directions, uint64_t
     return RVB_OK;
 }
 
-int rvb_trace(rvb_ctx * ctx, const float mic[3], const float source[3], uint64_t nreflections,
-              const float air_coefficient[8], uint64_t ray_offset)
+static int trace_common(rvb_ctx * ctx, const float * mics, const float * sources, uint64_t npairs, uint64_t nreflections,
+                        const float air_coefficient[8], uint64_t ray_offset)
 {
-    if (!ctx) return RVB_ERR_INVALID;
-    if (!mic || !source || !air_coefficient) return fail(ctx, RVB_ERR_INVALID, "rvb_trace: null argument");
     if (!ctx->have_scene) return fail(ctx, RVB_ERR_STATE, "rvb_trace: rvb_set_scene has not been called");
     if (!ctx->directions && ctx->nrays) return fail(ctx, RVB_ERR_STATE, "rvb_trace: no directions");
-    if (nreflections >= (1ull << 31) || ctx->nrays * 9 >= (1ull << 32))
+    if (nreflections >= (1ull << 31) || ctx->nrays * npairs * 9 >= (1ull << 32))
         return fail(ctx, RVB_ERR_CAPACITY, "rvb_trace: too many reflections or rays for one context");
+    const float * mic = mics, * source = sources;
     RVB_BIND(ctx);
-    const uint64_t nrays = ctx->nrays;
+    const uint64_t nrays = ctx->nrays * npairs;       // rays of this launch
     const size_t imp_bytes = (size_t) nrays * nreflections * sizeof(rvb_impulse);
     const size_t early_bytes = (size_t) nrays * 9 * sizeof(uint32_t);
     RVB_HIP(ctx, ctx->impulses.ensure(imp_bytes));
@@ -349,8 +361,30 @@ int rvb_trace(rvb_ctx * ctx, const float mic[3], const float source[3], uint64_t
     a.candidates = ctx->candidates.as<rvb_image_candidate>();
     a.candidate_count = reinterpret_cast<uint32_t *>(ctx->small.as<char>() + kSmallCandidateCount);
     a.direct = reinterpret_cast<rvb_impulse *>(ctx->small.as<char>() + kSmallDirect);
+    a.npairs = (uint32_t) npairs;
+    a.rays_per_pair = (uint32_t) ctx->nrays;
+    a.pair_mics = nullptr;
+    a.pair_sources = nullptr;
     a.executed = reinterpret_cast<unsigned long long *>(ctx->small.as<char>() + kSmallExecuted);
     a.time_range = reinterpret_cast<uint32_t *>(ctx->small.as<char>() + kSmallTraceRange);
+    if (npairs > 1) {
+        // several pairs per launch: geometry, direct path and time range per pair live in arrays of their own
+        std::vector<float> geom(8 * npairs, 0.0f);
+        for (uint64_t p = 0; p < npairs; ++p)
+            for (int i = 0; i < 3; ++i) { geom[4 * p + i] = mics[3 * p + i]; geom[4 * (npairs + p) + i] = sources[3 * p + i]; }
+        RVB_HIP(ctx, ctx->pair_geom.ensure(geom.size() * sizeof(float)));
+        RVB_HIP(ctx, ctx->pair_direct.ensure(npairs * sizeof(rvb_impulse)));
+        RVB_HIP(ctx, ctx->pair_range.ensure(npairs * 2 * sizeof(uint32_t)));
+        RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));                      // geom is a stack-local staging vector
+        RVB_HIP(ctx, hipMemcpy(ctx->pair_geom.p, geom.data(), geom.size() * sizeof(float), hipMemcpyHostToDevice));
+        std::vector<uint32_t> init(2 * npairs);
+        for (uint64_t p = 0; p < npairs; ++p) { init[2 * p] = 0xFFFFFFFFu; init[2 * p + 1] = 0u; }
+        RVB_HIP(ctx, hipMemcpy(ctx->pair_range.p, init.data(), init.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        a.pair_mics = ctx->pair_geom.as<float4>();
+        a.pair_sources = ctx->pair_geom.as<float4>() + npairs;
+        a.direct = ctx->pair_direct.as<rvb_impulse>();
+        a.time_range = ctx->pair_range.as<uint32_t>();
+    }
     // record bucketing for coherent shadow rays (RVB_SHADOW_SORT=0 turns it off)
     static const bool sort_records = !(getenv("RVB_SHADOW_SORT") && getenv("RVB_SHADOW_SORT")[0] == '0');
     const uint64_t nrecords = nrays * nreflections;
@@ -364,7 +398,7 @@ int rvb_trace(rvb_ctx * ctx, const float mic[3], const float source[3], uint64_t
         RVB_HIP(ctx, ctx->sort_keys.ensure(nrecords * 4));
         RVB_HIP(ctx, ctx->sort_scratch.ensure(nrecords * 4));
         RVB_HIP(ctx, ctx->sort_order.ensure(nrecords * 4));
-        const size_t group_bytes = rvb_group_records_temp_bytes(nrecords);
+        const size_t group_bytes = rvb_group_records_temp_bytes(ctx->nrays * nreflections);
         if (group_bytes == 0) return fail(ctx, RVB_ERR_HIP, "rvb_trace: radix sort size query failed");
         RVB_HIP(ctx, ctx->group_temp.ensure(group_bytes));
         // slots of escaped rays get key 0xFFFFFFFF from path_kernel: they land in the last bucket and the
@@ -404,8 +438,12 @@ int rvb_trace(rvb_ctx * ctx, const float mic[3], const float source[3], uint64_t
         ctx->begin_timing("record_sort_kernels");
         a.sort_order = ctx->sort_order.as<uint32_t>();
         RVB_HIP(ctx, hipGetLastError());
-        RVB_HIP(ctx, rvb_group_records(ctx->group_temp.p, ctx->group_temp.cap, a.sort_keys, ctx->sort_scratch.as<uint32_t>(), a.sort_order,
-                                       nrecords, std::max(0, key_bits - group_bits), key_bits, ctx->stream));
+        // one grouping per pair (a pair's shadow rays share a microphone; records are [pair][ray][bounce])
+        const uint64_t per_pair = ctx->nrays * nreflections;
+        for (uint64_t p = 0; p < npairs; ++p)
+            RVB_HIP(ctx, rvb_group_records(ctx->group_temp.p, ctx->group_temp.cap, a.sort_keys + p * per_pair,
+                                           ctx->sort_scratch.as<uint32_t>() + p * per_pair, a.sort_order + p * per_pair, per_pair,
+                                           (uint32_t) (p * per_pair), std::max(0, key_bits - group_bits), key_bits, ctx->stream));
         ctx->end_timing();
     }
     RVB_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_done, 0));
@@ -417,6 +455,37 @@ int rvb_trace(rvb_ctx * ctx, const float mic[3], const float source[3], uint64_t
     ctx->traced = true;
     ctx->small_valid = false;
     ctx->ir_configured = false;
+    ctx->npairs = npairs;
+    ctx->traced_rays = nrays;
+    ctx->ir_pair = 0;
+    ctx->pair_mics_host.assign(mics, mics + 3 * npairs);
+    return RVB_OK;
+}
+
+int rvb_trace(rvb_ctx * ctx, const float mic[3], const float source[3], uint64_t nreflections,
+              const float air_coefficient[8], uint64_t ray_offset)
+{
+    if (!ctx) return RVB_ERR_INVALID;
+    if (!mic || !source || !air_coefficient) return fail(ctx, RVB_ERR_INVALID, "rvb_trace: null argument");
+    return trace_common(ctx, mic, source, 1, nreflections, air_coefficient, ray_offset);
+}
+
+int rvb_trace_pairs(rvb_ctx * ctx, const float * mics, const float * sources, uint64_t npairs, uint64_t nreflections,
+                    const float air_coefficient[8], uint64_t ray_offset)
+{
+    if (!ctx) return RVB_ERR_INVALID;
+    if (!mics || !sources || !air_coefficient || npairs == 0) return fail(ctx, RVB_ERR_INVALID, "rvb_trace_pairs: null argument or no pairs");
+    return trace_common(ctx, mics, sources, npairs, nreflections, air_coefficient, ray_offset);
+}
+
+int rvb_ir_select_pair(rvb_ctx * ctx, uint64_t pair)
+{
+    if (!ctx) return RVB_ERR_INVALID;
+    if (!ctx->traced) return fail(ctx, RVB_ERR_STATE, "rvb_ir_select_pair: nothing traced");
+    if (pair >= ctx->npairs) return fail(ctx, RVB_ERR_INVALID, "rvb_ir_select_pair: pair out of range");
+    ctx->ir_pair = pair;
+    ctx->ir_configured = false;
+    for (int i = 0; i < 3; ++i) ctx->mic[i] = ctx->pair_mics_host[3 * pair + i];
     return RVB_OK;
 }
 
@@ -426,10 +495,16 @@ static int fetch_small(rvb_ctx * ctx)
     if (ctx->small_valid)
         return RVB_OK;
     RVB_HIP(ctx, hipMemcpyAsync(ctx->small_host, ctx->small.p, kSmallBytes, hipMemcpyDeviceToHost, ctx->stream));
-    if (ctx->nrays)      // capacity nrays * 9 >= 32 entries unless there are fewer than 4 rays
+    if (ctx->traced_rays)      // capacity rays * 9 >= 32 entries unless there are fewer than 4 rays
         RVB_HIP(ctx, hipMemcpyAsync(ctx->first_candidates, ctx->candidates.p,
-                                    std::min(sizeof(ctx->first_candidates), (size_t) ctx->nrays * 9 * sizeof(rvb_image_candidate)),
+                                    std::min(sizeof(ctx->first_candidates), (size_t) ctx->traced_rays * 9 * sizeof(rvb_image_candidate)),
                                     hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->npairs > 1) {     // per-pair direct paths and time ranges
+        ctx->pair_direct_host.resize(ctx->npairs);
+        ctx->pair_range_host.resize(2 * ctx->npairs);
+        RVB_HIP(ctx, hipMemcpyAsync(ctx->pair_direct_host.data(), ctx->pair_direct.p, ctx->npairs * sizeof(rvb_impulse), hipMemcpyDeviceToHost, ctx->stream));
+        RVB_HIP(ctx, hipMemcpyAsync(ctx->pair_range_host.data(), ctx->pair_range.p, ctx->npairs * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    }
     RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->small_valid = true;
     return RVB_OK;
@@ -441,7 +516,7 @@ int rvb_get_diffuse(rvb_ctx * ctx, rvb_impulse * out)
     if (!ctx->traced) return fail(ctx, RVB_ERR_STATE, "rvb_get_diffuse: nothing traced");
     RVB_BIND(ctx);
     RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const size_t bytes = (size_t) ctx->nrays * ctx->nreflections * sizeof(rvb_impulse);
+    const size_t bytes = (size_t) ctx->traced_rays * ctx->nreflections * sizeof(rvb_impulse);
     if (bytes) {
         if (!out) return fail(ctx, RVB_ERR_INVALID, "rvb_get_diffuse: null output");
         RVB_HIP(ctx, hipMemcpy(out, ctx->impulses.p, bytes, hipMemcpyDeviceToHost));
@@ -454,7 +529,7 @@ int rvb_diffuse_device(rvb_ctx * ctx, const void ** d_impulses, uint64_t * count
     if (!ctx) return RVB_ERR_INVALID;
     if (!ctx->traced) return fail(ctx, RVB_ERR_STATE, "rvb_diffuse_device: nothing traced");
     if (d_impulses) *d_impulses = ctx->impulses.p;
-    if (count) *count = ctx->nrays * ctx->nreflections;
+    if (count) *count = ctx->traced_rays * ctx->nreflections;
     return RVB_OK;
 }
 
@@ -465,7 +540,8 @@ int rvb_get_direct(rvb_ctx * ctx, rvb_impulse * out)
     RVB_BIND(ctx);
     int rc = fetch_small(ctx);
     if (rc != RVB_OK) return rc;
-    std::memcpy(out, ctx->small_host + kSmallDirect, sizeof(rvb_impulse));
+    if (ctx->npairs > 1) *out = ctx->pair_direct_host[ctx->ir_pair];       // of the pair chosen with rvb_ir_select_pair
+    else std::memcpy(out, ctx->small_host + kSmallDirect, sizeof(rvb_impulse));
     return RVB_OK;
 }
 
@@ -747,7 +823,8 @@ int rvb_ir_time_range(rvb_ctx * ctx, float * min_nonzero_time, float * max_time)
         if (ctx->which & RVB_IR_DIFFUSE) {
             int rc = fetch_small(ctx);
             if (rc != RVB_OK) return rc;
-            std::memcpy(got, ctx->small_host + kSmallTraceRange, sizeof(got));
+            if (ctx->npairs > 1) { got[0] = ctx->pair_range_host[2 * ctx->ir_pair]; got[1] = ctx->pair_range_host[2 * ctx->ir_pair + 1]; }
+            else std::memcpy(got, ctx->small_host + kSmallTraceRange, sizeof(got));
         }
         float lo = 0.0f, hi = 0.0f;
         bool have_lo = got[0] != 0xFFFFFFFFu;
@@ -771,7 +848,7 @@ int rvb_ir_time_range(rvb_ctx * ctx, float * min_nonzero_time, float * max_time)
     ctx->reset_timings();
     ctx->begin_timing("time_range_kernel");
     if (ctx->which & RVB_IR_DIFFUSE)
-        rvb_launch_time_range(ctx->model, ctx->impulses.as<rvb_impulse>(), ctx->nrays * ctx->nreflections, range, ctx->stream);
+        rvb_launch_time_range(ctx->model, ir_diffuse(ctx), ctx->nrays * ctx->nreflections, range, ctx->stream);
     if (ctx->which & RVB_IR_IMAGES)
         rvb_launch_time_range(ctx->model, ctx->images.as<rvb_impulse>(), ctx->nimages, range, ctx->stream);
     ctx->end_timing();
@@ -808,7 +885,7 @@ int rvb_ir_accumulate(rvb_ctx * ctx, float predelay, float sample_rate, uint64_t
         RVB_HIP(ctx, ctx->acc.ensure(acc_bytes));
         RVB_HIP(ctx, hipMemsetAsync(ctx->acc.p, 0, acc_bytes, ctx->stream));
         ctx->begin_timing("histogram_fast_kernel");
-        rvb_launch_histogram_fast(m, ctx->impulses.as<rvb_impulse>(), ndiffuse, predelay, sample_rate, nbins, ctx->acc.as<float>(), ctx->stream);
+        rvb_launch_histogram_fast(m, ir_diffuse(ctx), ndiffuse, predelay, sample_rate, nbins, ctx->acc.as<float>(), ctx->stream);
         rvb_launch_histogram_fast(m, ctx->images.as<rvb_impulse>(), nimages, predelay, sample_rate, nbins, ctx->acc.as<float>(), ctx->stream);
         ctx->end_timing();
         ctx->begin_timing("histogram_transpose_kernel");
@@ -821,13 +898,13 @@ int rvb_ir_accumulate(rvb_ctx * ctx, float predelay, float sample_rate, uint64_t
         if (rc != RVB_OK) return rc;
         ctx->begin_timing("exact_mode");
         for (uint32_t ch = 0; ch < m.nchannels; ++ch) {
-            rvb_launch_bin_keys(m, ch, ctx->impulses.as<rvb_impulse>(), ndiffuse, 0, predelay, sample_rate,
+            rvb_launch_bin_keys(m, ch, ir_diffuse(ctx), ndiffuse, 0, predelay, sample_rate,
                                 ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), ctx->stream);
             rvb_launch_bin_keys(m, ch, ctx->images.as<rvb_impulse>(), nimages, ndiffuse, predelay, sample_rate,
                                 ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), ctx->stream);
             rvb_sort_pairs(ctx->sort_temp.p, ctx->sort_temp.cap, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(),
                            ctx->vals_a.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), n, 32, ctx->stream);
-            rvb_launch_ordered_sum(m, ch, ctx->impulses.as<rvb_impulse>(), ndiffuse, ctx->images.as<rvb_impulse>(), nimages,
+            rvb_launch_ordered_sum(m, ch, ir_diffuse(ctx), ndiffuse, ctx->images.as<rvb_impulse>(), nimages,
                                    ctx->keys_b.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), n, nbins,
                                    hist + (size_t) ch * 8 * nbins, ctx->stream);
         }

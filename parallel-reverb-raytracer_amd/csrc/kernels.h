@@ -37,6 +37,12 @@ struct TraceArgs {
     uint32_t stack_entries;             // LDS traversal stack entries per lane (BuiltScene::stack_need)
     uint32_t lds_surfaces;              // surfaces staged in LDS behind the stack by the quad kernels (rvb_lds_surfaces), 0 = none
     uint32_t scene_nodes;               // number of BVH nodes (experiments that stage the top of the tree)
+    // Several (source, microphone) pairs in ONE launch (rvb_trace_pairs): ray r belongs to pair r / rays_per_pair and uses
+    // direction r % rays_per_pair; its records, early ids, candidates follow the global ray number.  npairs == 1: mic / source below.
+    uint32_t npairs;
+    uint32_t rays_per_pair;
+    const float4 * pair_mics;           // device [npairs] (xyz, w unused); direct[] and time_range[] then hold one entry per pair
+    const float4 * pair_sources;
     uint64_t ray_offset;
     float mic[3];
     float source[3];
@@ -57,7 +63,7 @@ void rvb_launch_shadow(const TraceArgs & a, hipStream_t s);
 // order[] lists the records bucket by bucket and the shadow kernel walks that list.
 size_t rvb_group_records_temp_bytes(uint64_t n);
 hipError_t rvb_group_records(void * temp, size_t temp_bytes, const uint32_t * keys, uint32_t * keys_scratch, uint32_t * order,
-                             uint64_t n, int begin_bit, int end_bit, hipStream_t s);
+                             uint64_t n, uint32_t first_record, int begin_bit, int end_bit, hipStream_t s);
 
 // ---- streaming kernels (stream_kernels.hip) ---------------------------------------------------
 struct AttenuationModel {

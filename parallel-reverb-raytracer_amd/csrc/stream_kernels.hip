@@ -575,9 +575,10 @@ size_t rvb_group_records_temp_bytes(uint64_t n)
 }
 
 hipError_t rvb_group_records(void * temp, size_t temp_bytes, const uint32_t * keys, uint32_t * keys_scratch, uint32_t * order,
-                             uint64_t n, int begin_bit, int end_bit, hipStream_t s)
+                             uint64_t n, uint32_t first_record, int begin_bit, int end_bit, hipStream_t s)
 {
     if (n == 0) return hipSuccess;
-    return rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_scratch, rocprim::counting_iterator<uint32_t>(0), order,
+    // values = record numbers first_record .. first_record + n (a slice of the launch's records)
+    return rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_scratch, rocprim::counting_iterator<uint32_t>(first_record), order,
                                      (size_t) n, (unsigned) begin_bit, (unsigned) end_bit, s);
 }

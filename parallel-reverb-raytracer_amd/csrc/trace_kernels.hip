@@ -571,6 +571,7 @@ struct PathJob {
     uint32_t index;
     bool alive;
     lds_float4_ptr surf_lds;             // the surface table staged in LDS (stage_surfaces); unused when !SURF_LDS
+    uint32_t pair_tag;                   // (source, microphone) pair of this ray + 1: what marks its work records as valid
 
     __device__ __forceinline__ bool next(v3 & o_, v3 & d_, float & tmax)
     {
@@ -602,7 +603,7 @@ struct PathJob {
         const float diff = fabsf(dot3(normal, d));                   // kernel.cpp:478
         float4 chunk = vol;
         if (c == 2) chunk = make_float4(p.x, p.y, p.z, diff);
-        else if (c == 3) chunk = make_float4(new_dist, __uint_as_float(surface), __uint_as_float(h.tri), __uint_as_float(1u));
+        else if (c == 3) chunk = make_float4(new_dist, __uint_as_float(surface), __uint_as_float(h.tri), __uint_as_float(pair_tag));   // tag: pair + 1, non-zero = valid
         const uint64_t record = (uint64_t) ray * a.nreflections + index;
         store_stream(reinterpret_cast<float4 *>(a.impulses + record) + c, chunk);
         if (c == 0 && index < RVB_NUM_IMAGE_SOURCE - 1)
@@ -639,9 +640,17 @@ __global__ __launch_bounds__(WAVE, 8) void path_kernel(TraceArgs a)
 #endif
     if (ray >= a.nrays)
         return;                                   // whole quads leave together
-    const float4 d4 = a.directions[ray];
-    PathJob<SURF_LDS> job = {a, (uint32_t) ray, threadIdx.x & 3u, ld3(a.source), mk3(d4.x, d4.y, d4.z), 0.0f,
-                   make_float4(1.0f, 1.0f, 1.0f, 1.0f), 0u, true, surf_lds};
+    uint32_t pair = 0, local = (uint32_t) ray;
+    v3 source = ld3(a.source);
+    if (a.npairs > 1) {                           // wave-uniform: several (source, microphone) pairs share the launch
+        pair = (uint32_t) ray / a.rays_per_pair;
+        local = (uint32_t) ray - pair * a.rays_per_pair;
+        const float4 s4 = a.pair_sources[pair];
+        source = mk3(s4.x, s4.y, s4.z);
+    }
+    const float4 d4 = a.directions[local];
+    PathJob<SURF_LDS> job = {a, (uint32_t) ray, threadIdx.x & 3u, source, mk3(d4.x, d4.y, d4.z), 0.0f,
+                   make_float4(1.0f, 1.0f, 1.0f, 1.0f), 0u, true, surf_lds, pair + 1u};
 #if RVB_PATH_JOBS == 2
 #if RVB_LDS_NODES
     traverse_jobs_vote(a.scene, stack_lds + q, job, lds_nodes);
@@ -734,9 +743,18 @@ __global__ __launch_bounds__(WAVE) void image_kernel(TraceArgs a)
     const uint32_t lane = threadIdx.x;
     uint32_t * stack = stack_lds + lane;
     const uint64_t ray = (uint64_t) blockIdx.x * WAVE + lane;
-    const v3 mic = ld3(a.mic), source = ld3(a.source);
+    v3 mic = ld3(a.mic), source = ld3(a.source);
+    uint32_t pair = 0;
+    bool first_of_pair = ray == 0;
+    if (a.npairs > 1 && ray < a.nrays) {
+        pair = (uint32_t) ray / a.rays_per_pair;
+        first_of_pair = (uint32_t) ray == pair * a.rays_per_pair;
+        const float4 m4 = a.pair_mics[pair], s4 = a.pair_sources[pair];
+        mic = mk3(m4.x, m4.y, m4.z);
+        source = mk3(s4.x, s4.y, s4.z);
+    }
 
-    if (ray == 0) {
+    if (first_of_pair) {
         // slot 0, the direct path (kernel.cpp:335-357): identical for every ray, computed once
         rvb_impulse direct;
         for (int b = 0; b < 8; ++b) direct.volume[b] = 0.0f;
@@ -747,7 +765,7 @@ __global__ __launch_bounds__(WAVE) void image_kernel(TraceArgs a)
             float one[8] = {1, 1, 1, 1, 1, 1, 1, 1};
             make_image(a, mic, mic, source, one, direct);
         }
-        *a.direct = direct;
+        a.direct[pair] = direct;
     }
     if (ray >= a.nrays)
         return;
@@ -838,6 +856,7 @@ struct ShadowJob {
     float diff, new_dist, mag;
     uint32_t surface;
     float tmin, tmax_seen;               // arrival-time range of the non-zero impulses this lane's quad produced
+    uint32_t pair;                       // pair of the current record (several pairs per launch only)
     lds_float4_ptr surf_lds;             // surface table in LDS; unused when !SURF_LDS
 
     __device__ __forceinline__ bool next(v3 & o_, v3 & d_, float & tmax)
@@ -849,8 +868,14 @@ struct ShadowJob {
             g += stride;
             mine = load_stream(rec + c);
             // chunk 3 = (newDist, surface, triangle, valid); chunk 2 = (intersection, DIFF)
-            if (quad_bcast_u<3>(__float_as_uint(mine.w)) != 1u)
+            const uint32_t tag = quad_bcast_u<3>(__float_as_uint(mine.w));
+            if (tag == 0u)
                 continue;                         // ray had already escaped: slot keeps its zero fill
+            if (a.npairs > 1) {                   // the record's pair: its microphone, its time range
+                const float4 m4 = a.pair_mics[tag - 1u];
+                mic = mk3(m4.x, m4.y, m4.z);
+                pair = tag - 1u;
+            }
             new_dist = quad_bcast_f<3>(mine.x);
             surface = quad_bcast_u<3>(__float_as_uint(mine.y));
             p = mk3(quad_bcast_f<2>(mine.x), quad_bcast_f<2>(mine.y), quad_bcast_f<2>(mine.z));
@@ -899,8 +924,17 @@ struct ShadowJob {
         const bool nonzero = quad_any(c < 2 && (o.x != 0.0f || o.y != 0.0f || o.z != 0.0f || o.w != 0.0f));
         if (nonzero) {
             const float t = seconds_per_meter() * dist;
-            if (t != 0.0f) tmin = fminf(tmin, t);
-            tmax_seen = fmaxf(tmax_seen, t);
+            if (a.npairs > 1) {
+                // one range per pair: a quad's lane 0 updates it, and only when a plain read says the value can still move
+                if (c == 0) {
+                    const volatile uint32_t * seen = a.time_range + 2u * pair;
+                    if (t != 0.0f && __float_as_uint(t) < seen[0]) atomicMin(a.time_range + 2u * pair, __float_as_uint(t));
+                    if (__float_as_uint(t) > seen[1]) atomicMax(a.time_range + 2u * pair + 1u, __float_as_uint(t));
+                }
+            } else {
+                if (t != 0.0f) tmin = fminf(tmin, t);
+                tmax_seen = fmaxf(tmax_seen, t);
+            }
         }
     }
 };
@@ -920,6 +954,7 @@ __global__ __launch_bounds__(WAVE, RVB_SHADOW_WAVES) void shadow_kernel(TraceArg
     job.stride = (uint64_t) gridDim.x * QUADS_PER_BLOCK;
     job.total = a.nrays * (uint64_t) a.nreflections;
     job.mic = ld3(a.mic);
+    job.pair = 0;
     job.airA = a.air[2 * c];
     job.airB = a.air[2 * c + 1];
     job.tmin = __builtin_inff();
@@ -942,7 +977,7 @@ __global__ __launch_bounds__(WAVE, RVB_SHADOW_WAVES) void shadow_kernel(TraceArg
         tmin = fminf(tmin, __shfl_xor(tmin, off));
         tmax_seen = fmaxf(tmax_seen, __shfl_xor(tmax_seen, off));
     }
-    if (threadIdx.x == 0) {                       // non-negative floats order like their bit patterns
+    if (threadIdx.x == 0 && a.npairs <= 1) {      // non-negative floats order like their bit patterns
         const volatile uint32_t * seen = a.time_range;    // skip the atomic when it cannot move the result (stale reads are harmless)
         if (tmin != __builtin_inff() && __float_as_uint(tmin) < seen[0]) atomicMin(a.time_range + 0, __float_as_uint(tmin));
         if (__float_as_uint(tmax_seen) > seen[1]) atomicMax(a.time_range + 1, __float_as_uint(tmax_seen));

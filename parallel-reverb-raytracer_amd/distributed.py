@@ -230,19 +230,59 @@ class IrPipeline:
 
 
 def generate_pair_irs(tracers, pairs, nreflections, air, model_for_pair, sample_rate, rank=0, world=1, device="cpu",
-                      trim_predelay=True, mode=capi.IR_FAST, which=capi.IR_ALL, remove_direct=False):
+                      trim_predelay=True, mode=capi.IR_FAST, which=capi.IR_ALL, remove_direct=False, pairs_per_launch=1):
     """BASELINE config C5: many (source, listener) pairs in one scene.  The PAIRS shard over the ranks (contiguous blocks,
-    shard_range) and every rank traces its own pairs with all of its rays — no collective at all; on a
-    rank the pairs run as jobs of the two-context pipeline.  `pairs` = [(mic, source)], `model_for_pair(i)` -> SpeakerModel /
-    HrtfModel of pair i; `tracers` = this rank's contexts (same scene and rays on each).  Returns {pair index: (hist, info)}
-    for this rank's pairs."""
+    shard_range) and every rank traces its own pairs with all of its rays — no collective at all.
+    `pairs` = [(mic, source)], `model_for_pair(i)` -> SpeakerModel / HrtfModel of pair i; `tracers` = this rank's contexts
+    (same scene and rays on each).  Returns {pair index: (hist, info)} for this rank's pairs.
+
+    pairs_per_launch == 1: the pairs are jobs of the two-context pipeline, one trace each.
+    pairs_per_launch > 1: that many pairs are traced in ONE launch (Context.trace_pairs: the path kernel runs with more waves per
+    SIMD), the next launch is enqueued on the other context before this launch's pairs are binned."""
+    import torch
     first, count = shard_range(len(pairs), rank, world)
-    jobs, out = [], {}
-    for i in range(first, first + count):
-        mic, source = pairs[i]
-        jobs.append(((mic, source, nreflections, air),
-                     dict(model=model_for_pair(i), sample_rate=sample_rate, trim_predelay=trim_predelay, mode=mode, device=device,
-                          which=which, remove_direct=remove_direct)))        # rank 0 / world 1 inside generate_ir: a pair is not sharded
-    order = list(range(first, first + count))
-    IrPipeline(tracers).run_jobs(jobs, lambda hist, info, _tracer: out.__setitem__(order[len(out)], (hist, info)))
+    out = {}
+    if pairs_per_launch <= 1:
+        jobs = []
+        for i in range(first, first + count):
+            mic, source = pairs[i]
+            jobs.append(((mic, source, nreflections, air),
+                         dict(model=model_for_pair(i), sample_rate=sample_rate, trim_predelay=trim_predelay, mode=mode, device=device,
+                              which=which, remove_direct=remove_direct)))    # rank 0 / world 1 inside generate_ir: a pair is not sharded
+        order = list(range(first, first + count))
+        IrPipeline(tracers).run_jobs(jobs, lambda hist, info, _tracer: out.__setitem__(order[len(out)], (hist, info)))
+        return out
+
+    batches = [list(range(b, min(first + count, b + pairs_per_launch))) for b in range(first, first + count, pairs_per_launch)]
+    n = len(tracers)
+
+    def begin(j):
+        tracers[j % n].trace_pairs([pairs[i][0] for i in batches[j]], [pairs[i][1] for i in batches[j]], nreflections, air)
+
+    if batches:
+        begin(0)
+    empty = np.zeros(0, dtype=IMPULSE)
+    for j, batch in enumerate(batches):
+        if j + 1 < len(batches) and n > 1:
+            begin(j + 1)
+        tracer = tracers[j % n]
+        candidates = tracer.get_image_candidates()           # all pairs of the launch, global ray numbers
+        for k, i in enumerate(batch):
+            tracer.select_pair(k)
+            images = empty
+            if which & capi.IR_IMAGES:
+                images = capi.merge_images(tracer.get_pair_candidates(k, candidates), tracer.get_direct(), remove_direct)
+            model = model_for_pair(i)
+            model.configure(tracer, pairs[i][0], which, images)
+            lo, hi = tracer.ir_time_range()
+            predelay = lo if trim_predelay else 0.0
+            nbins = tracer.ir_bins(hi, predelay, sample_rate)
+            hist = torch.zeros((model.nchannels, 8, nbins), device=device, dtype=torch.float32)
+            tracer.ir_accumulate_tensor(predelay, sample_rate, nbins, mode, hist)
+            out[i] = (hist, {"nbins": nbins, "predelay": predelay, "images": int(images.shape[0]), "max_time": hi})
+        if n == 1 and j + 1 < len(batches):
+            tracer.synchronize()                             # the next launch reuses this context's buffers
+            begin(j + 1)
+        else:
+            tracer.synchronize()
     return out

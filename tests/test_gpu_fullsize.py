@@ -154,5 +154,65 @@ def test_c5_pairs_through_the_two_context_pipeline_equal_one_at_a_time(ctx):
         for (h0, n0, i0), (h1, n1, i1) in zip(alone, got):
             assert n0 == n1 and i0 == i1 and np.array_equal(h0, h1)
         assert any(h.any() for h, _, _ in got)
+
+        # the same pairs through generate_pair_irs, three pairs per launch (rvb_trace_pairs), launches alternating between contexts
+        def model_for(i):
+            return job(pairs[i])[1]["model"]
+        batched = distributed.generate_pair_irs([ctx, other], [(mic[p], src[p]) for p in pairs], nrefl, AIR_COEFFICIENTS, model_for,
+                                                44100.0, device=device, mode=capi.IR_EXACT, pairs_per_launch=3)
+        assert sorted(batched) == list(range(len(pairs)))
+        for k in range(len(pairs)):
+            hist, info = batched[k]
+            assert info["nbins"] == alone[k][1] and info["images"] == alone[k][2] and np.array_equal(hist.cpu().numpy(), alone[k][0])
     finally:
         other.close()
+
+
+def test_pairs_in_one_launch_equal_pairs_one_by_one(ctx):
+    """rvb_trace_pairs: several (source, microphone) pairs of one hall traced in ONE launch give, pair by pair, the bytes that
+    tracing each pair alone gives — raw impulses, image-source candidates, direct path — and the same exact-mode IR, for the
+    speaker model and for HRTF."""
+    from parallel_reverb_raytracer_amd import capi
+    scene, _ = scenes.concert_hall(30000)
+    src, mic = scenes.source_mic_pairs(64, seed=0)
+    table = scenes.hrtf_synthetic_table()
+    nrays, nrefl, pairs = 5000, 24, [3, 11, 40, 41, 63]           # 5000: not a multiple of the 16 rays per wave
+    dirs = scenes.sphere_directions(nrays, seed=7)
+    ctx.set_scene(scene)
+    ctx.set_directions(dirs)
+
+    def irs(p):
+        images = capi.merge_images(cands, ctx.get_direct(), False)
+        out = []
+        ctx.ir_configure_speakers(mic[p], [(-1, 0, -1), (1, 0, -1)], [0.5, 0.5], capi.IR_ALL, images)
+        out.append(ctx.ir_download(True, 44100.0, capi.IR_EXACT))
+        facing = src[p] - mic[p]
+        ctx.ir_configure_hrtf(mic[p], table, facing / np.linalg.norm(facing), (0, 1, 0), capi.IR_ALL, images)
+        out.append(ctx.ir_download(True, 44100.0, capi.IR_EXACT))
+        return images, out
+
+    alone = []
+    for p in pairs:
+        ctx.trace(mic[p], src[p], nrefl, AIR_COEFFICIENTS)
+        cands = ctx.get_image_candidates()
+        diffuse = ctx.get_raw_diffuse()
+        images, ir = irs(p)
+        alone.append((diffuse, cands, ctx.get_direct(), images, ir))
+
+    ctx.trace_pairs(mic[pairs], src[pairs], nrefl, AIR_COEFFICIENTS)
+    everything = ctx.get_raw_diffuse().reshape(len(pairs), nrays * nrefl)
+    all_cands = ctx.get_image_candidates()
+    assert all_cands.shape[0] == sum(a[1].shape[0] for a in alone)
+    for k, p in enumerate(pairs):
+        diffuse, cands_alone, direct, images_alone, ir_alone = alone[k]
+        assert _same(everything[k], diffuse)
+        ctx.select_pair(k)
+        cands = ctx.get_pair_candidates(k, all_cands)
+        assert np.array_equal(cands["ray"], cands_alone["ray"]) and np.array_equal(cands["slot"], cands_alone["slot"])
+        assert np.array_equal(cands["index"], cands_alone["index"]) and _same(cands["impulse"], cands_alone["impulse"])
+        assert _same(ctx.get_direct(), direct)
+        images, ir = irs(p)
+        assert _same(images, images_alone)
+        for a, b in zip(ir, ir_alone):
+            assert a.shape == b.shape and np.array_equal(a, b)
+    assert any(a[4][0].any() for a in alone)

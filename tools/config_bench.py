@@ -96,6 +96,20 @@ def pairs_pipelined(scene, src, mic, nrays, nrefl, npairs):
             c.synchronize()
         torch.cuda.synchronize()
         out[label + "_ms_per_pair"] = (time.perf_counter() - t0) * 1e3 / npairs
+    # the same pairs, 4 and 8 per launch (Context.trace_pairs), the launches alternating between the two contexts
+    pair_list = [(mic[p], src[p]) for p in range(npairs)]
+
+    def model_for(p):
+        facing = src[p] - mic[p]
+        return distributed.HrtfModel(table, facing / np.linalg.norm(facing), (0, 1, 0))
+
+    for per_launch in (4, 8):
+        distributed.generate_pair_irs(ctxs, pair_list, nrefl, dtypes.AIR_COEFFICIENTS, model_for, 44100.0, device=device, pairs_per_launch=per_launch)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        distributed.generate_pair_irs(ctxs, pair_list, nrefl, dtypes.AIR_COEFFICIENTS, model_for, 44100.0, device=device, pairs_per_launch=per_launch)
+        torch.cuda.synchronize()
+        out["%d_pairs_per_launch_ms_per_pair" % per_launch] = (time.perf_counter() - t0) * 1e3 / npairs
     for c in ctxs:
         c.close()
     out.update({"config": "C5 per-GPU share: %d pairs, concert-hall stand-in, %d rays x %d, HRTF" % (npairs, nrays, nrefl),
