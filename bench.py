@@ -225,7 +225,8 @@ def main():
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
             if (nrays, nrefl, args.triangles, world) == (100000, 128, 75000, 1):
-                traffic = {k: v["hbm_bytes_per_launch"] for k, v in pmc["kernels"].items() if "hbm_bytes_per_launch" in v}
+                # per IR: the binning kernel runs twice per IR (diffuse impulses, then the few image sources) under one timing label
+                traffic = {k: v.get("hbm_bytes_per_ir", v["hbm_bytes_per_launch"]) for k, v in pmc["kernels"].items() if "hbm_bytes_per_launch" in v}
                 valu_insts = {k: v["SQ_INSTS_VALU"] for k, v in pmc["kernels"].items() if "SQ_INSTS_VALU" in v}
                 valu_per_ir = pmc.get("valu_wave_instructions_per_ir")
         except (OSError, ValueError, KeyError):

@@ -66,6 +66,9 @@ for s, c in pmc.items():
         c["valu_active_share_of_wave_cycles"] = c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else None
         c["wait_any_share_of_wave_cycles"] = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") and "SQ_WAIT_ANY" in c else None
 irs = pmc.get("path_kernel", {}).get("_launches", 0)
+for c in pmc.values():                                   # a kernel launched more than once per IR (binning: diffuse + images)
+    if "hbm_bytes_per_launch" in c and irs:
+        c["hbm_bytes_per_ir"] = c["hbm_bytes_per_launch"] * c.get("_launches", irs) / irs
 step_kernels = [k for k in pmc if k != "attenuate_kernel"]          # the attenuate probe runs outside the timed steps
 valu_per_ir = sum(pmc[k].get("SQ_INSTS_VALU_all_launches", 0.0) for k in step_kernels) / irs if irs else None
 json.dump({"irs_in_command": irs, "valu_wave_instructions_per_ir": valu_per_ir, "_how": "tools/profile.sh %s: rocprofv3 --kernel-trace --pmc <one set per pass> -- python3 bench.py --steps 3 --warmup 1 "
