@@ -133,6 +133,9 @@ int rvb_attenuate_hrtf(rvb_ctx * ctx, const float mic[3], const rvb_impulse * in
                        const float * table /* [360*180*8] for this ear */,
                        const float facing[3], const float up[3], uint64_t channel,
                        rvb_attenuated_impulse * out);
+/* ... and HrtfAttenuator::attenuate's kernel on device-resident buffers (table is host memory as above). */
+int rvb_attenuate_hrtf_device(rvb_ctx * ctx, const float mic[3], const void * d_in, uint64_t n,
+                              const float * table, const float facing[3], const float up[3], uint64_t channel, void * d_out);
 
 /* ---- time binning, materialised: replaces flattenImpulses (rayverb.cpp:48-77) for one channel.
  * Bit-exact with the reference's serial summation order.  out is [8][*nbins]. */

@@ -27,7 +27,7 @@ SYMBOLS = [
     "rvb_set_scene", "rvb_scene_info", "rvb_set_directions", "rvb_set_directions_device", "rvb_trace",
     "rvb_trace_pairs", "rvb_ir_select_pair",
     "rvb_get_diffuse", "rvb_diffuse_device", "rvb_get_direct", "rvb_get_image_candidates", "rvb_merge_images",
-    "rvb_attenuate_speaker", "rvb_attenuate_speaker_device", "rvb_attenuate_hrtf", "rvb_flatten",
+    "rvb_attenuate_speaker", "rvb_attenuate_speaker_device", "rvb_attenuate_hrtf", "rvb_attenuate_hrtf_device", "rvb_flatten",
     "rvb_ir_configure_speakers", "rvb_ir_configure_hrtf", "rvb_ir_time_range", "rvb_ir_bins", "rvb_ir_accumulate",
     "rvb_ir_download", "rvb_last_timings", "rvb_debug_stamps", "rvb_executed_bounces",
 ]
@@ -256,6 +256,13 @@ class Context:
         """The materialised `attenuate` kernel on HBM-resident buffers (device addresses), asynchronous."""
         sp = make_speakers([direction], [coefficient])
         self._check(self.lib.rvb_attenuate_speaker_device(self.handle, _f3(mic), _vp(d_in), _u64(n), _ptr(sp), _vp(d_out)))
+
+    def attenuate_hrtf_device(self, mic, d_in, n, table_channel, facing, up, channel, d_out):
+        """The materialised `hrtf` kernel on HBM-resident buffers (device addresses), asynchronous."""
+        table = np.ascontiguousarray(table_channel, dtype=np.float32).reshape(-1)
+        assert table.shape[0] == 360 * 180 * 8
+        self._check(self.lib.rvb_attenuate_hrtf_device(self.handle, _f3(mic), _vp(d_in), _u64(n), _ptr(table), _f3(facing), _f3(up),
+                                                       _u64(channel), _vp(d_out)))
 
     def attenuate_hrtf(self, mic, impulses, table_channel, facing, up, channel):
         imp = np.ascontiguousarray(impulses, dtype=IMPULSE)

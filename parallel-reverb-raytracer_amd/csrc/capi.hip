@@ -706,6 +706,33 @@ int rvb_attenuate_hrtf(rvb_ctx * ctx, const float mic[3], const rvb_impulse * in
     return run_attenuate(ctx, m, (uint32_t) channel, in, n, out);
 }
 
+int rvb_attenuate_hrtf_device(rvb_ctx * ctx, const float mic[3], const void * d_in, uint64_t n,
+                              const float * table, const float facing[3], const float up[3], uint64_t channel, void * d_out)
+{
+    if (!ctx) return RVB_ERR_INVALID;
+    if (!mic || !table || !facing || !up || channel > 1) return fail(ctx, RVB_ERR_INVALID, "rvb_attenuate_hrtf_device: bad argument");
+    if (n && (!d_in || !d_out)) return fail(ctx, RVB_ERR_INVALID, "rvb_attenuate_hrtf_device: null buffer");
+    if (n && d_in == d_out) return fail(ctx, RVB_ERR_INVALID, "rvb_attenuate_hrtf_device: in-place is not supported");
+    RVB_BIND(ctx);
+    RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));           // the table image is about to be replaced
+    std::vector<float> both((size_t) 2 * 360 * 180 * 8, 0.0f);
+    std::memcpy(both.data() + (size_t) channel * 360 * 180 * 8, table, (size_t) 360 * 180 * 8 * sizeof(float));
+    int rc = upload_hrtf_table(ctx, both.data(), 2);
+    if (rc != RVB_OK) return rc;
+    AttenuationModel m;
+    m.hrtf = 1;
+    m.nchannels = 2;
+    m.hrtf_table = ctx->hrtf_table.as<const float>();
+    for (int i = 0; i < 3; ++i) { m.mic[i] = mic[i]; m.facing[i] = facing[i]; m.up[i] = up[i]; }
+    ctx->ir_configured = false;
+    ctx->reset_timings();
+    ctx->begin_timing("attenuate_kernel");
+    rvb_launch_attenuate(m, (uint32_t) channel, reinterpret_cast<const rvb_impulse *>(d_in), n, reinterpret_cast<rvb_attenuated_impulse *>(d_out), ctx->stream);
+    ctx->end_timing();
+    RVB_HIP(ctx, hipGetLastError());
+    return RVB_OK;
+}
+
 static int ensure_sort_buffers(rvb_ctx * ctx, uint64_t n)
 {
     RVB_HIP(ctx, ctx->keys_a.ensure(n * 4));

@@ -267,6 +267,19 @@ def test_attenuate_speaker_device_entry_equals_host_entry(ctx, oracle):
     nz = imp["volume"].any(axis=1)
     assert np.array_equal(got["volume"][nz], ref["volume"][nz]) and np.array_equal(got["time"][nz], ref["time"][nz])
     assert not got["volume"][~nz].any() and not got["time"][~nz].any()
+    # the HRTF kernel through its device entry, both ears
+    table = scenes.hrtf_synthetic_table()
+    facing, up = (0.6, 0.0, 0.8), (0.0, 1.0, 0.0)
+    for ear in (0, 1):
+        want_h = ctx.attenuate_hrtf(mic, imp, table[ear], facing, up, ear)
+        d_out.fill_(0xCD)
+        torch.cuda.synchronize()
+        ctx.attenuate_hrtf_device(mic, d_in.data_ptr(), n, table[ear], facing, up, ear, d_out.data_ptr())
+        ctx.synchronize()
+        got_h = d_out.cpu().numpy().view(dtypes.ATTENUATED)
+        assert np.array_equal(got_h["volume"], want_h["volume"]) and np.array_equal(got_h["time"], want_h["time"])
+        ref_h = oracle.attenuate_hrtf(mic, imp, table[ear], facing, up, ear)
+        assert np.array_equal(got_h["volume"][nz], ref_h["volume"][nz]) and np.array_equal(got_h["time"][nz], ref_h["time"][nz])
 
 
 def test_attenuate_hrtf_matches_golden(ctx):
