@@ -34,6 +34,8 @@ struct ModelDev {
     float coeff[8];
     const float * table;    // [2][360*180+1][8]
     v3 pointing, up;
+    v3 bx, by, bz;          // the listener's basis of kernel.cpp:538-549 — it depends on (pointing, up) only, so it is computed once
+                            // on the host with the same operations (rvb_math.h is shared) instead of once per impulse
     v3 ear[2];              // kernel.cpp:599-603
 };
 
@@ -59,6 +61,9 @@ ModelDev make_model(const AttenuationModel & m)
     d.table = m.hrtf_table;
     d.pointing = mk3(m.facing[0], m.facing[1], m.facing[2]);
     d.up = mk3(m.up[0], m.up[1], m.up[2]);
+    d.bx = normalize3(cross3(d.up, d.pointing));
+    d.by = cross3(d.pointing, d.bx);
+    d.bz = d.pointing;
     const float width = 0.1f;                                   // kernel.cpp:597
     d.ear[0] = transform3(d.pointing, d.up, mk3(-width, 0.0f, 0.0f)) + d.mic;
     d.ear[1] = transform3(d.pointing, d.up, mk3(width, 0.0f, 0.0f)) + d.mic;
@@ -75,9 +80,15 @@ __device__ __forceinline__ float speaker_gain(const ModelDev & m, uint32_t ch, v
 }
 
 // reference kernel.cpp:563-584: table row selected for an impulse at `pos` (same for both ears)
+// transform (kernel.cpp:538-549) with the precomputed basis: the three dot products that remain per impulse
+__device__ __forceinline__ v3 to_listener(const ModelDev & m, v3 d)
+{
+    return mk3(dot3(m.bx, d), dot3(m.by, d), dot3(m.bz, d));
+}
+
 __device__ __forceinline__ int64_t hrtf_row(const ModelDev & m, v3 pos)
 {
-    const v3 t = transform3(m.pointing, m.up, normalize3(pos - m.mic));
+    const v3 t = to_listener(m, normalize3(pos - m.mic));
     const float az = atan2_cr(t.x, t.z);
     const float el = atan2_cr(t.y, sqrtf(t.x * t.x + t.z * t.z));
     int64_t a = (int64_t) (az * 57.295779513082320877f + 180);
@@ -85,6 +96,26 @@ __device__ __forceinline__ int64_t hrtf_row(const ModelDev & m, v3 pos)
     int64_t e = (int64_t) (el * 57.295779513082320877f);
     e = 90 - e;
     return a * 180 + e;     // e == 180 runs into the next azimuth row (quirk Q5); row 360*180 is zero padding
+}
+
+// The same row for a quad that shares one impulse: azimuth and elevation are both atan2(y, x) of different arguments, so the
+// even lanes evaluate the azimuth and the odd lanes the elevation with ONE call (it is ~150 double-precision instructions),
+// then swap by DPP.  Same operations on the same operands as hrtf_row.
+template <int CTRL> __device__ __forceinline__ float qdpp_f(float v);
+__device__ __forceinline__ int64_t hrtf_row_quad(const ModelDev & m, v3 pos, uint32_t q)
+{
+    const v3 t = to_listener(m, normalize3(pos - m.mic));
+    const bool odd = q & 1u;
+    const float y = odd ? t.y : t.x;
+    const float x = odd ? sqrtf(t.x * t.x + t.z * t.z) : t.z;
+    const float deg = atan2_cr(y, x) * 57.295779513082320877f;
+    const float other = qdpp_f<0xB1>(deg);                     // quad_perm [1,0,3,2]: the pair lane's angle
+    const float az_deg = odd ? other : deg, el_deg = odd ? deg : other;
+    int64_t a = (int64_t) (az_deg + 180);
+    a %= 360;
+    int64_t e = (int64_t) el_deg;
+    e = 90 - e;
+    return a * 180 + e;
 }
 
 // reference kernel.cpp:616-622: arrival-time shift of one ear
@@ -162,7 +193,7 @@ __device__ __forceinline__ float4 attenuate_chunk_hrtf(const ModelDev & m, uint3
     float4 o = make_float4(0, 0, 0, 0);
     if (nz) {
         const v3 pos = mk3(px, py, pz);
-        const int64_t row = hrtf_row(m, pos);
+        const int64_t row = hrtf_row_quad(m, pos, q);
         if (q < 2) {
             const float4 t = reinterpret_cast<const float4 *>(m.table + ((uint64_t) ch * (360 * 180 + 1) + (uint64_t) row) * 8)[q];
             o = make_float4(v.x * t.x, v.y * t.y, v.z * t.z, v.w * t.w);
