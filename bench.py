@@ -48,8 +48,8 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     p.add_argument("--rehearse-collectives", action="store_true",
                    help="with one rank: create the process group anyway and run every collective of the multi-GPU path on it")
-    p.add_argument("--contexts", type=int, default=2, help="contexts per GPU that alternate IRs (2: the trace of IR i+1 runs beside the "
-                   "grouping / binning / host stages of IR i; 1: strictly one IR at a time)")
+    p.add_argument("--contexts", type=int, default=4, help="contexts per GPU that take turns (4: the traces of IRs i+2, i+3 are enqueued "
+                   "together, beside the grouping / binning / host stages of IRs i, i+1; 2: plain alternation; 1: strictly one IR at a time)")
     return p.parse_args()
 
 
@@ -272,7 +272,8 @@ def main():
                                    % (scene[0].shape[0], nrays, nrefl, sr, args.mode),
                        "triangles": int(scene[0].shape[0]), "rays_per_gpu": nrays, "reflections": nrefl,
                        "sharding": "ray-range shards, replicated scene, one all-reduce(sum) of [2][8][nbins] histograms",
-                       "pipelining": "%d contexts per GPU alternate IRs: the trace of IR i+1 is enqueued before IR i is finished" % len(contexts)},
+                       "pipelining": "%d contexts per GPU take turns: traces are enqueued %d at a time, the next group before the current one is finished"
+                                     % (len(contexts), max(1, len(contexts) // 2))},
             "ir_gen_wall_ms": solo_latency_ms, "contexts_per_gpu": len(contexts),
             "trace_only_ray_bounces_per_sec": (nrays * nrefl) / (trace_ms * 1e-3) if trace_ms else None,
             "executed_bounces_rank0": int(executed), "nominal_bounces_rank0": nrays * nrefl,

@@ -284,21 +284,27 @@ __global__ __launch_bounds__(256) void time_range_kernel(ModelDev m, const float
 #define HIST_ROW 20     // LDS words per staged impulse: 16 record words + padding (b128-aligned, 4-way conflicts at most)
 #define HIST_MAXCH 8
 
-__global__ __launch_bounds__(256) void histogram_fast_kernel(ModelDev m, const float4 * __restrict__ in, uint64_t n,
+// HIST_WAVES waves per workgroup, each with a staging area of its own (no cross-wave traffic).  One-wave workgroups: when
+// another impulse response's path_kernel holds 24 of a CU's 32 wave slots (IrPipeline), a four-wave workgroup finds room on a
+// CU only now and then, single waves slip into the free slots.
+#ifndef HIST_WAVES
+#define HIST_WAVES 1
+#endif
+__global__ __launch_bounds__(64 * HIST_WAVES) void histogram_fast_kernel(ModelDev m, const float4 * __restrict__ in, uint64_t n,
                                                              float predelay, float sample_rate, uint64_t nbins,
                                                              float * __restrict__ acc)
 {
-    __shared__ __attribute__((aligned(16))) float stage[4][64 * HIST_ROW];      // the wave's 64 records
-    __shared__ float gains[4][64 * HIST_MAXCH];
-    __shared__ uint32_t bins[4][64 * 2];                                        // speakers: one bin; hrtf: one per ear
+    __shared__ __attribute__((aligned(16))) float stage[HIST_WAVES][64 * HIST_ROW];      // the wave's 64 records
+    __shared__ float gains[HIST_WAVES][64 * HIST_MAXCH];
+    __shared__ uint32_t bins[HIST_WAVES][64 * 2];                                        // speakers: one bin; hrtf: one per ear
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     float * st = stage[wave];
     float * gn = gains[wave];
     uint32_t * bn = bins[wave];
-    const uint64_t nwaves = (uint64_t) gridDim.x * 4;
+    const uint64_t nwaves = (uint64_t) gridDim.x * HIST_WAVES;
     const uint64_t ngroups = (n + 63) / 64;
     const uint32_t f = lane & 15u, band = f & 7u, chsel = f >> 3;
-    for (uint64_t grp = (uint64_t) blockIdx.x * 4 + wave; grp < ngroups; grp += nwaves) {
+    for (uint64_t grp = (uint64_t) blockIdx.x * HIST_WAVES + wave; grp < ngroups; grp += nwaves) {
         const uint64_t first = grp * 64;
         // stage 64 records (4 KiB) with four fully coalesced 1-KiB wave loads
 #pragma unroll
@@ -534,7 +540,7 @@ void rvb_launch_histogram_fast(const AttenuationModel & m, const rvb_impulse * i
                                float sample_rate, uint64_t nbins, float * acc, hipStream_t s)
 {
     if (n == 0) return;
-    hipLaunchKernelGGL(histogram_fast_kernel, dim3(stream_blocks(n, 256)), dim3(256), 0, s, make_model(m),
+    hipLaunchKernelGGL(histogram_fast_kernel, dim3(stream_blocks(n, 64 * HIST_WAVES)), dim3(64 * HIST_WAVES), 0, s, make_model(m),
                        reinterpret_cast<const float4 *>(in), n, predelay, sample_rate, nbins, acc);
 }
 

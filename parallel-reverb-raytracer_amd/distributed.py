@@ -206,21 +206,30 @@ class IrPipeline:
             begin_ir(self.tracers[slot], *trace_args, ray_offset=ir_kwargs.get("ray_offset", 0))
             self.begun[slot] = True
 
-        # Jobs are enqueued in GROUPS of `group` traces (their path kernels then run side by side: more waves per SIMD, see
-        # DESIGN.md "rays per launch"), and group j+1 is enqueued before group j is finished.  group = len(tracers) // 2;
-        # two contexts: group 1 = the plain alternation.
+        # Default schedule: jobs are enqueued in GROUPS of `group` traces (their path kernels then run side by side: more waves
+        # per SIMD, see DESIGN.md "rays per launch"), and group j+1 is enqueued before group j is finished.  group =
+        # len(tracers) // 2; two contexts: group 1 = the plain alternation.  RVB_PIPELINE_AHEAD=k instead keeps k traces
+        # enqueued ahead of the IR being finished (k < len(tracers)).
         group = max(1, n // 2) if n > 1 else 1
         group = min(group, int(__import__("os").environ.get("RVB_PIPELINE_GROUP", group)))       # (an override may only shrink it)
+        ahead = min(n - 1, int(__import__("os").environ.get("RVB_PIPELINE_AHEAD", 0)))
+        begun_upto = [0]                                     # jobs [0, begun_upto) have been begun
 
-        def begin_group(j):
-            for k in range(j * group, min((j + 1) * group, len(jobs))):
-                begin(k)
+        def begin_upto(k):
+            while begun_upto[0] < min(k, len(jobs)):
+                begin(begun_upto[0])
+                begun_upto[0] += 1
 
-        begin_group(0)
+        begin_upto(group if ahead <= 0 else 1 + ahead)
         for i, (trace_args, ir_kwargs) in enumerate(jobs):
             slot = (first + i) % n
-            if n > 1 and i % group == 0:
-                begin_group(i // group + 1)
+            if n > 1:
+                if ahead > 0:
+                    begin_upto(i + 1 + ahead)
+                elif i % group == 0:
+                    begin_upto((i // group + 2) * group)
+            else:
+                begin_upto(i + 1)
             began = self.begun[slot]
             self.begun[slot] = False
             hist, info = generate_ir(self.tracers[slot], *trace_args, begun=began, **ir_kwargs)
