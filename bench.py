@@ -29,14 +29,14 @@ from parallel_reverb_raytracer_amd import capi, distributed, dtypes, scenes  # n
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 4   # 256 CUs x 4 SIMDs, one VALU wave-instruction per 4 cycles at 2.4 GHz = 614.4 G/s
-PMC_FILE = "r01d_pmc_n1.json"
+PMC_FILE = "r01e_pmc_n1.json"
 
 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=5)
-    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=4)
     p.add_argument("--rays", type=int, default=100000, help="rays per GPU")
     p.add_argument("--reflections", type=int, default=128)
     p.add_argument("--triangles", type=int, default=75000)
