@@ -203,6 +203,23 @@ def test_triangle_soup_matches_brute_force(ctx, oracle, seed):
     assert np.count_nonzero(want["time"]) > 100                       # the case is not vacuous: rays do hit and see the microphone
 
 
+@pytest.mark.parametrize("nrays,nrefl", [(1, 1), (1, 700), (17, 333), (32, 1000)])
+def test_long_chains_and_tiny_launches(ctx, oracle, nrays, nrefl):
+    """One ray, a partial quad group, and chains far longer than the bench's 128 bounces (the job loop keeps a ray's state for
+    the whole chain; volumes shrink towards denormals, which are kept)."""
+    scene = scenes.rotated_square_room(n=3)
+    mic, src = (1.0, 3.0, -2.0), (-2.0, 5.0, 1.5)
+    dirs = scenes.sphere_directions(nrays, seed=nrays + nrefl)
+    ctx.set_scene(scene)
+    ctx.raytrace(mic, src, dirs, nrefl, AIR_COEFFICIENTS)
+    want, image, index = oracle.raytrace(scene, mic, src, dirs, nrefl, AIR_COEFFICIENTS)
+    assert_impulses_equal(ctx.get_raw_diffuse(), want, "%d rays x %d" % (nrays, nrefl))
+    assert_impulses_equal(ctx.get_raw_images(True), oracle.collect_images(image, index, True), "images")
+    # (a ray may leak through an edge of the closed room exactly as it does in the brute-force scan: the slots after that are empty)
+    executed = int(np.count_nonzero(want["position"][:, :3].any(axis=1) | (want["time"] != 0) | want["volume"].any(axis=1)))
+    assert executed <= ctx.executed_bounces() <= nrays * nrefl
+
+
 def test_edge_cases_empty_and_ragged(ctx, oracle):
     scene = scenes.rotated_square_room(n=1)
     ctx.set_scene(scene)
