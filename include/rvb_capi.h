@@ -153,8 +153,12 @@ int rvb_flatten(rvb_ctx * ctx, const rvb_attenuated_impulse * in, uint64_t n, fl
  *                         caller all-reduces (min, max) before step 3.
  * 3. rvb_ir_accumulate    adds this context's impulses into d_histogram [nchannels][8][nbins]
  *                         (device memory, caller-zeroed, float).  mode RVB_IR_FAST uses float
- *                         atomics (order-dependent in the last bits); RVB_IR_EXACT reproduces the
- *                         reference's serial summation order bit for bit (single context only).
+ *                         atomics (order-dependent in the last bits); RVB_IR_EXACT continues, bin by
+ *                         bin, the reference's serial left-to-right float sum (rayverb.cpp:67-74) from
+ *                         the values d_histogram holds: on a zeroed histogram that IS flattenImpulses
+ *                         bit for bit, and contexts that hold consecutive ray shards reproduce the
+ *                         single-context result when they accumulate into the same histogram in shard
+ *                         order (diffuse shards first, the merged image sources last).
  */
 enum { RVB_IR_DIFFUSE = 1, RVB_IR_IMAGES = 2, RVB_IR_ALL = 3 };   /* OutputMode, config.h:19-23 */
 enum { RVB_IR_FAST = 0, RVB_IR_EXACT = 1 };

@@ -923,17 +923,23 @@ int rvb_ir_accumulate(rvb_ctx * ctx, float predelay, float sample_rate, uint64_t
         if (n >= (1ull << 32)) return fail(ctx, RVB_ERR_CAPACITY, "rvb_ir_accumulate: too many impulses for exact mode");
         int rc = ensure_sort_buffers(ctx, n);
         if (rc != RVB_OK) return rc;
+        if (nbins >= 0xFFFFFFFFull) return fail(ctx, RVB_ERR_CAPACITY, "rvb_ir_accumulate: too many bins for exact mode");
+        // keys are bins, nbins itself marks "adds nothing": key_bits_for(nbins) bits cover 0 .. nbins
+        const int bits = key_bits_for(nbins);
+        const uint32_t sentinel = (uint32_t) nbins;
         ctx->begin_timing("exact_mode");
-        for (uint32_t ch = 0; ch < m.nchannels; ++ch) {
-            rvb_launch_bin_keys(m, ch, ir_diffuse(ctx), ndiffuse, 0, predelay, sample_rate,
+        // speaker channels keep the input time (kernel.cpp:530-533): one sorted list serves them all; the two ears of the
+        // HRTF model shift the time differently (kernel.cpp:616-622) and get a list each
+        const uint32_t lists = m.hrtf ? m.nchannels : 1u;
+        for (uint32_t ch = 0; ch < lists; ++ch) {
+            rvb_launch_bin_keys(m, ch, ir_diffuse(ctx), ndiffuse, 0, predelay, sample_rate, sentinel,
                                 ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), ctx->stream);
-            rvb_launch_bin_keys(m, ch, ctx->images.as<rvb_impulse>(), nimages, ndiffuse, predelay, sample_rate,
+            rvb_launch_bin_keys(m, ch, ctx->images.as<rvb_impulse>(), nimages, ndiffuse, predelay, sample_rate, sentinel,
                                 ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), ctx->stream);
             rvb_sort_pairs(ctx->sort_temp.p, ctx->sort_temp.cap, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(),
-                           ctx->vals_a.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), n, 32, ctx->stream);
-            rvb_launch_ordered_sum(m, ch, ir_diffuse(ctx), ndiffuse, ctx->images.as<rvb_impulse>(), nimages,
-                                   ctx->keys_b.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), n, nbins,
-                                   hist + (size_t) ch * 8 * nbins, ctx->stream);
+                           ctx->vals_a.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), n, bits, ctx->stream);
+            rvb_launch_ordered_sum(m, ch, m.hrtf ? 1u : m.nchannels, ir_diffuse(ctx), ndiffuse, ctx->images.as<rvb_impulse>(), nimages,
+                                   ctx->keys_b.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), n, nbins, hist, ctx->stream);
         }
         ctx->end_timing();
     } else {

@@ -87,13 +87,14 @@ void rvb_launch_histogram_fast(const AttenuationModel & m, const rvb_impulse * i
                                float sample_rate, uint64_t nbins, float * acc, hipStream_t s);
 // acc[bin][channel][band] -> hist[channel][band][bin] (added to what is there)
 void rvb_launch_histogram_transpose(const float * acc, float * hist, uint32_t nchannels, uint64_t nbins, hipStream_t s);
-// exact mode helpers: per-impulse bin keys, then the ordered per-bin summation
+// exact mode helpers: per-impulse bin keys (`sentinel` = nbins marks impulses that add nothing), then the ordered per-bin
+// summation of `nchannels` channels that share the sorted list, added to what hist [all channels][8][nbins] holds
 void rvb_launch_bin_keys(const AttenuationModel & m, uint32_t channel, const rvb_impulse * in, uint64_t n, uint64_t index_base,
-                         float predelay, float sample_rate, uint32_t * keys, uint32_t * values, hipStream_t s);
-void rvb_launch_ordered_sum(const AttenuationModel & m, uint32_t channel, const rvb_impulse * diffuse, uint64_t ndiffuse,
-                            const rvb_impulse * images, uint64_t nimages,
+                         float predelay, float sample_rate, uint32_t sentinel, uint32_t * keys, uint32_t * values, hipStream_t s);
+void rvb_launch_ordered_sum(const AttenuationModel & m, uint32_t first_channel, uint32_t nchannels, const rvb_impulse * diffuse,
+                            uint64_t ndiffuse, const rvb_impulse * images, uint64_t nimages,
                             const uint32_t * sorted_keys, const uint32_t * sorted_values, uint64_t n,
-                            uint64_t nbins, float * hist_channel, hipStream_t s);
+                            uint64_t nbins, float * hist, hipStream_t s);
 // flattenImpulses of already attenuated impulses (rayverb.cpp:48-77): keys + ordered sum
 void rvb_launch_flat_keys(const rvb_attenuated_impulse * in, uint64_t n, float sample_rate, uint32_t * keys, uint32_t * values,
                           uint32_t * max_time_bits, hipStream_t s);

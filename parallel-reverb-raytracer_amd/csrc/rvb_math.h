@@ -125,6 +125,9 @@ RVB_HD void mirror_verts(TriVerts & in, const TriVerts & t)
 // The "* 1" of kernel.cpp:210-213 is exact.
 RVB_HD float air_attenuation(float distance, float air)
 {
+#if defined(RVB_EXP_PROBE)          // diagnostic builds only (wrong values): what the kernels cost WITHOUT the exponential
+    return 1.0f + distance * air;
+#endif
     // ln((float) M_E) = ln(2.71828174591064453125) = 0.99999996963214001827215631464059433...
     const double ln_e_hi = 0x1.fffffefb245eap-1;
     const double ln_e_lo = 0x1.a2d208d1c4e82p-56;      // ln(e_f) - ln_e_hi

@@ -395,8 +395,10 @@ __global__ __launch_bounds__(256) void histogram_transpose_kernel(const float * 
 }
 
 // ---- exact mode -------------------------------------------------------------------------------
+// Key of an impulse = its bin; `sentinel` (= nbins, the first value past every bin) for an impulse that adds nothing.
+// Keys therefore need key_bits_for(nbins) bits only (20 at workload C2 instead of 32: three radix passes instead of four).
 __global__ __launch_bounds__(256) void bin_keys_kernel(ModelDev m, uint32_t ch, const rvb_impulse * __restrict__ in, uint64_t n,
-                                                       uint64_t index_base, float predelay, float sample_rate,
+                                                       uint64_t index_base, float predelay, float sample_rate, uint32_t sentinel,
                                                        uint32_t * __restrict__ keys, uint32_t * __restrict__ values)
 {
     for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
@@ -406,11 +408,11 @@ __global__ __launch_bounds__(256) void bin_keys_kernel(ModelDev m, uint32_t ch, 
         const bool nonzero = v0.x != 0.0f || v0.y != 0.0f || v0.z != 0.0f || v0.w != 0.0f
                           || v1.x != 0.0f || v1.y != 0.0f || v1.z != 0.0f || v1.w != 0.0f;
         // A zero-volume impulse attenuates to {0, 0} (quirk Q2): the reference adds its zeros to bin 0, which changes nothing
-        // (x + 0 = x, and a sum that starts at +0 never becomes -0).  It gets the key 0xFFFFFFFF — sorted last, matched by no
+        // (x + 0 = x, and a sum that starts at +0 never becomes -0).  It gets the sentinel key — sorted last, matched by no
         // bin — instead of bin 0: the blocked third of all shadow rays would otherwise make ONE lane of ordered_sum_kernel walk
         // millions of entries (2.2 s at workload C2).
-        uint32_t key = 0xFFFFFFFFu;
-        if (nonzero) key = time_bin(attenuated_time(m, ch, mk3(p.x, p.y, p.z), time), predelay, sample_rate);
+        uint32_t key = sentinel;
+        if (nonzero) key = min(time_bin(attenuated_time(m, ch, mk3(p.x, p.y, p.z), time), predelay, sample_rate), sentinel);
         keys[index_base + i] = key;
         values[index_base + i] = (uint32_t) (index_base + i);
     }
@@ -426,9 +428,14 @@ __device__ __forceinline__ uint64_t lower_bound_u32(const uint32_t * a, uint64_t
     return lo;
 }
 
-// One lane per bin: add the bin's impulses in impulse order (the order of rayverb.cpp:67-74).
-__global__ __launch_bounds__(64) void ordered_sum_kernel(ModelDev m, uint32_t ch, const rvb_impulse * __restrict__ diffuse, uint64_t ndiffuse,
-                                                         const rvb_impulse * __restrict__ images,
+// One lane per bin: add the bin's impulses in impulse order (the order of rayverb.cpp:67-74) ON TOP of what the histogram
+// holds (the caller zeroes it; a second context that continues the fold with the next ray shard starts from the first one's
+// sums, so the chain reproduces the serial order over all shards).  Speaker channels keep the input time (kernel.cpp:530-533)
+// and share the bin, so ONE sorted list serves NCH channels of the speaker model (first_channel .. first_channel + NCH - 1);
+// the two ears of the HRTF model have their own bins (NCH = 1, one list per ear).
+template <bool HRTF, int NCH>
+__global__ __launch_bounds__(64) void ordered_sum_kernel(ModelDev m, uint32_t first_channel, const rvb_impulse * __restrict__ diffuse,
+                                                         uint64_t ndiffuse, const rvb_impulse * __restrict__ images,
                                                          const uint32_t * __restrict__ keys, const uint32_t * __restrict__ values,
                                                          uint64_t n, uint64_t nbins, float * __restrict__ hist)
 {
@@ -436,28 +443,39 @@ __global__ __launch_bounds__(64) void ordered_sum_kernel(ModelDev m, uint32_t ch
     if (bin >= nbins)
         return;
     const uint64_t lo = lower_bound_u32(keys, n, (uint32_t) bin);
-    float sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (lo >= n || keys[lo] != (uint32_t) bin)
+        return;                               // nothing lands in this bin: the histogram keeps what it holds
+    float sum[NCH][8];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+            sum[c][b] = hist[((uint64_t) (first_channel + c) * 8 + b) * nbins + bin];
     for (uint64_t k = lo; k < n && keys[k] == (uint32_t) bin; ++k) {
         const uint64_t idx = values[k];
         const rvb_impulse * imp = idx < ndiffuse ? diffuse + idx : images + (idx - ndiffuse);
         const float4 * r = reinterpret_cast<const float4 *>(imp);
         const float4 v0 = r[0], v1 = r[1], p = r[2];
         const float vol[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-        bool nonzero = false;
-        for (int b = 0; b < 8; ++b) nonzero = nonzero || vol[b] != 0.0f;
-        if (!nonzero)
-            continue;                         // adds +0 in the reference: no effect on the sums
-        const v3 pos = mk3(p.x, p.y, p.z);
-        if (m.hrtf) {
-            const float * t = m.table + ((uint64_t) ch * (360 * 180 + 1) + (uint64_t) hrtf_row(m, pos)) * 8;
-            for (int b = 0; b < 8; ++b) sum[b] += vol[b] * t[b];
+        const v3 pos = mk3(p.x, p.y, p.z);      // (keyed into a bin: the volume is non-zero)
+        if (HRTF) {
+            const float * t = m.table + ((uint64_t) first_channel * (360 * 180 + 1) + (uint64_t) hrtf_row(m, pos)) * 8;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) sum[0][b] += vol[b] * t[b];
         } else {
-            const float g = speaker_gain(m, ch, pos);
-            for (int b = 0; b < 8; ++b) sum[b] += vol[b] * g;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const float g = speaker_gain(m, first_channel + c, pos);
+#pragma unroll
+                for (int b = 0; b < 8; ++b) sum[c][b] += vol[b] * g;
+            }
         }
     }
-    for (int b = 0; b < 8; ++b)
-        hist[(uint64_t) b * nbins + bin] = sum[b];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+            hist[((uint64_t) (first_channel + c) * 8 + b) * nbins + bin] = sum[c][b];
 }
 
 __global__ __launch_bounds__(256) void flat_keys_kernel(const rvb_attenuated_impulse * __restrict__ in, uint64_t n, float sample_rate,
@@ -551,22 +569,37 @@ void rvb_launch_histogram_transpose(const float * acc, float * out, uint32_t nch
 }
 
 void rvb_launch_bin_keys(const AttenuationModel & m, uint32_t channel, const rvb_impulse * in, uint64_t n, uint64_t index_base,
-                         float predelay, float sample_rate, uint32_t * keys, uint32_t * values, hipStream_t s)
+                         float predelay, float sample_rate, uint32_t sentinel, uint32_t * keys, uint32_t * values, hipStream_t s)
 {
     if (n == 0) return;
     hipLaunchKernelGGL(bin_keys_kernel, dim3(stream_blocks(n, 256)), dim3(256), 0, s, make_model(m), channel, in, n,
-                       index_base, predelay, sample_rate, keys, values);
+                       index_base, predelay, sample_rate, sentinel, keys, values);
 }
 
-void rvb_launch_ordered_sum(const AttenuationModel & m, uint32_t channel, const rvb_impulse * diffuse, uint64_t ndiffuse,
-                            const rvb_impulse * images, uint64_t nimages,
+void rvb_launch_ordered_sum(const AttenuationModel & m, uint32_t first_channel, uint32_t nchannels, const rvb_impulse * diffuse,
+                            uint64_t ndiffuse, const rvb_impulse * images, uint64_t nimages,
                             const uint32_t * sorted_keys, const uint32_t * sorted_values, uint64_t n,
-                            uint64_t nbins, float * hist_channel, hipStream_t s)
+                            uint64_t nbins, float * hist, hipStream_t s)
 {
     (void) nimages;
-    if (nbins == 0) return;
-    hipLaunchKernelGGL(ordered_sum_kernel, dim3((unsigned) ((nbins + 63) / 64)), dim3(64), 0, s, make_model(m), channel,
-                       diffuse, ndiffuse, images, sorted_keys, sorted_values, n, nbins, hist_channel);
+    if (nbins == 0 || n == 0) return;
+    const dim3 grid((unsigned) ((nbins + 63) / 64)), block(64);
+    const ModelDev md = make_model(m);
+#define RVB_SUM(HRTF, NCH) hipLaunchKernelGGL((ordered_sum_kernel<HRTF, NCH>), grid, block, 0, s, md, first_channel, diffuse, ndiffuse, \
+                                              images, sorted_keys, sorted_values, n, nbins, hist)
+    if (m.hrtf) { RVB_SUM(true, 1); return; }
+    switch (nchannels) {                       // speaker channels of one sorted list
+    case 1: RVB_SUM(false, 1); break;
+    case 2: RVB_SUM(false, 2); break;
+    case 3: RVB_SUM(false, 3); break;
+    case 4: RVB_SUM(false, 4); break;
+    default:                                   // more than four: in groups (64 accumulators per lane would spill)
+        for (uint32_t c = 0; c < nchannels; c += 4) {
+            const uint32_t k = nchannels - c < 4 ? nchannels - c : 4;
+            rvb_launch_ordered_sum(m, first_channel + c, k, diffuse, ndiffuse, images, nimages, sorted_keys, sorted_values, n, nbins, hist, s);
+        }
+    }
+#undef RVB_SUM
 }
 
 void rvb_launch_flat_keys(const rvb_attenuated_impulse * in, uint64_t n, float sample_rate, uint32_t * keys, uint32_t * values,

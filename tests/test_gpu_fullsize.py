@@ -76,6 +76,64 @@ def test_c2_cathedral_100k_x_128_sampled_against_oracle(ctx, oracle):
     assert _crc(ctx.get_raw_diffuse()) == _crc(full)
 
 
+def fast_vs_exact_report(fast, exact):
+    """How far the float-atomic histogram is from the serial-order one: the claimed tolerance is 1e-5 x the band's largest
+    |value| (sign-alternating volumes cancel inside a bin, so a purely relative bar per band-bin is not
+    meaningful where the sum is ~0); also reported: the fraction of band-bins outside a pure 1e-5 RELATIVE error."""
+    fast64, exact64 = fast.astype(np.float64), exact.astype(np.float64)
+    err = np.abs(fast64 - exact64)
+    band_max = np.abs(exact64).max(axis=2, keepdims=True)                  # [channels][8][1]
+    nonzero = exact64 != 0
+    rel = np.zeros_like(err)
+    rel[nonzero] = err[nonzero] / np.abs(exact64[nonzero])
+    outside = (rel > 1e-5) | (~nonzero & (err > 0))
+    return {"max_abs_err_over_band_max": float((err / np.maximum(band_max, 1e-300)).max()),
+            "fraction_band_bins_outside_1e-5_relative": float(outside.mean()),
+            "max_relative_err_where_exact_nonzero": float(rel.max()),
+            "band_bins": int(err.size), "band_bins_differing": int((err > 0).sum())}
+
+
+def test_c2_final_ir_exact_mode_equals_oracle_chain_and_fast_mode_is_within_tolerance(ctx, oracle):
+    """BASELINE config C2 at full size, the FINAL impulse response: the traced impulses are downloaded and run through the
+    oracle's chain attenuate -> findPredelay / fixPredelay -> flattenImpulses on the CPU (reference cmd/main.cpp:280-298,
+    rayverb.h:49-97, rayverb.cpp:48-77); the exact-mode [2][8][nbins] histogram must be bit-equal to it, and the
+    float-atomic (fast) histogram within 1e-5 of each band's maximum."""
+    import json
+    import os
+    from parallel_reverb_raytracer_amd import capi
+    scene, info = scenes.cathedral(75000)
+    mic, src = info["mic"], info["source"]
+    nrays, nrefl, sr = 100000, 128, 44100.0
+    speakers = [((-1, 0, -1), 0.5), ((1, 0, -1), 0.5)]                   # bench.py's two cardioids
+    ctx.set_scene(scene)
+    ctx.raytrace(mic, src, scenes.sphere_directions(nrays, seed=1), nrefl, AIR_COEFFICIENTS)
+    images = ctx.get_raw_images(False)
+    all_raw = np.concatenate([ctx.get_raw_diffuse(), images])
+    chans = [oracle.attenuate_speaker(mic, all_raw, d, c) for d, c in speakers]
+    del all_raw
+    pd = oracle.find_predelay(chans)
+    flat = []
+    for c in chans:
+        oracle.fix_predelay(c, pd)
+        flat.append(oracle.flatten(c, sr))
+    del chans
+    ctx.ir_configure_speakers(mic, [s[0] for s in speakers], [s[1] for s in speakers], capi.IR_ALL, images)
+    exact = ctx.ir_download(True, sr, capi.IR_EXACT)
+    assert exact.shape == (2, 8, max(f.shape[1] for f in flat)) and exact.shape[2] > 500000
+    for ch in range(2):
+        n = flat[ch].shape[1]
+        assert np.array_equal(exact[ch][:, :n], flat[ch]), ch
+        assert not exact[ch][:, n:].any()
+    fast = ctx.ir_download(True, sr, capi.IR_FAST)
+    assert fast.shape == exact.shape
+    report = fast_vs_exact_report(fast, exact)
+    print("fast_vs_exact at C2:", json.dumps(report))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        json.dump(report, open(os.path.join(out, "fast_vs_exact_c2.json"), "w"))
+    assert report["max_abs_err_over_band_max"] <= 1e-5
+
+
 def test_c4_atrium_262k_triangles_256_bounces(ctx, oracle):
     scene, info = scenes.atrium(262000)
     assert scene[0].shape[0] > 250000

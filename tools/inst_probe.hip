@@ -46,6 +46,48 @@ BODY(and_or, A_ANDOR) BODY(bcnt, A_BCNT) BODY(cndmask, A_CNDMASK) BODY(cmp, A_CM
 BODY(mul_u24, A_MUL24) BODY(bitop3, A_BITOP3) BODY(cvt_f16, A_CVT) BODY(rcp, A_RCP) BODY(sqrt, A_SQRT) BODY(min, A_MIN)
 BODY(div_fixup, A_DIVFIX) BODY(bpermute, A_BPERM)
 
+
+// ---- binary64 forms (the correctly rounded exp of rvb_math.h air_attenuation is made of these) ----
+#define BODY64(NAME, ASM)                                                                            \
+    __global__ __launch_bounds__(256) void k_##NAME(float * out, int iters)                           \
+    {                                                                                                 \
+        double a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;  \
+        double b = 1.0001, c = 0.5;                                                                   \
+        for (int i = 0; i < iters; ++i) {                                                             \
+            asm volatile(ASM(0) ASM(1) ASM(2) ASM(3) ASM(4) ASM(5) ASM(6) ASM(7)                      \
+                         ASM(0) ASM(1) ASM(2) ASM(3) ASM(4) ASM(5) ASM(6) ASM(7)                      \
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc"); \
+        }                                                                                             \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = (float) (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7);  \
+    }
+#define A_FMA64(n) "v_fma_f64 %" #n ", %" #n ", %8, %9\n"
+#define A_MUL64(n) "v_mul_f64 %" #n ", %" #n ", %8\n"
+#define A_ADD64(n) "v_add_f64 %" #n ", %" #n ", %8\n"
+#define A_RNDNE64(n) "v_rndne_f64 %" #n ", %" #n "\n"
+#define A_LDEXP64(n) "v_ldexp_f64 %" #n ", %" #n ", 1\n"
+// conversions between a 64-bit pair (operand n) and a 32-bit register (operand n + 8)
+#define BODY64M(NAME, ASM)                                                                           \
+    __global__ __launch_bounds__(256) void k_##NAME(float * out, int iters)                           \
+    {                                                                                                 \
+        double a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;  \
+        float f0 = a0, f1 = a1, f2 = a2, f3 = a3, f4 = a4, f5 = a5, f6 = a6, f7 = a7;                 \
+        for (int i = 0; i < iters; ++i) {                                                             \
+            asm volatile(ASM(0, 8) ASM(1, 9) ASM(2, 10) ASM(3, 11) ASM(4, 12) ASM(5, 13) ASM(6, 14) ASM(7, 15)   \
+                         ASM(0, 8) ASM(1, 9) ASM(2, 10) ASM(3, 11) ASM(4, 12) ASM(5, 13) ASM(6, 14) ASM(7, 15)   \
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7),       \
+                           "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5), "+v"(f6), "+v"(f7));      \
+        }                                                                                             \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = (float) (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7) + f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7;  \
+    }
+#define A_CVT3264(n, m) "v_cvt_f32_f64 %" #m ", %" #n "\n"
+#define A_CVT6432(n, m) "v_cvt_f64_f32 %" #n ", %" #m "\n"
+#define A_CVTI64(n, m) "v_cvt_i32_f64 %" #m ", %" #n "\n"
+#define A_RCP64(n) "v_rcp_f64 %" #n ", %" #n "\n"
+#define A_MINU64(n) "v_cmp_lt_u64 vcc, %" #n ", %8\n"
+BODY64(fma_f64, A_FMA64) BODY64(mul_f64, A_MUL64) BODY64(add_f64, A_ADD64) BODY64(rndne_f64, A_RNDNE64) BODY64(ldexp_f64, A_LDEXP64)
+BODY64M(cvt_f32_f64, A_CVT3264) BODY64M(cvt_f64_f32, A_CVT6432) BODY64M(cvt_i32_f64, A_CVTI64) BODY64(rcp_f64, A_RCP64) BODY64(cmp_u64, A_MINU64)
+
+static int g_blocks_per_cu = 8;
 template <class K> float run(K kernel, float * out)
 {
     hipEvent_t a, b;
@@ -53,7 +95,7 @@ template <class K> float run(K kernel, float * out)
     float best = 1e9f;
     for (int r = 0; r < 4; ++r) {
         hipEventRecord(a);
-        hipLaunchKernelGGL(kernel, dim3(256 * 8), dim3(256), 0, 0, out, 4096);      // 8 blocks x 4 waves per CU = 8 waves per SIMD
+        hipLaunchKernelGGL(kernel, dim3(256 * g_blocks_per_cu), dim3(256), 0, 0, out, 4096);      // g_blocks_per_cu blocks x 4 waves per CU = that many waves per SIMD
         hipEventRecord(b);
         hipEventSynchronize(b);
         float ms;
@@ -67,10 +109,20 @@ int main()
 {
     float * out;
     hipMalloc(&out, 256 * 8 * 256 * sizeof(float));
-    const float base = run(k_fma, out);
-    printf("v_fma_f32        %.3f ms = 1.00\n", base);
-#define SHOW(NAME) printf("%-16s %.3f ms = %.2f\n", #NAME, run(k_##NAME, out), run(k_##NAME, out) / base);
-    SHOW(fma_mix) SHOW(perm) SHOW(min_dpp) SHOW(mov_dpp) SHOW(max3) SHOW(and_or) SHOW(bcnt) SHOW(cndmask) SHOW(cmp) SHOW(lshl_add)
-    SHOW(mul_lo) SHOW(mul_u24) SHOW(bitop3) SHOW(cvt_f16) SHOW(rcp) SHOW(sqrt) SHOW(min) SHOW(div_fixup) SHOW(bpermute)
+    // cycles per wave-instruction per SIMD = time x clock / (instructions per wave x waves per SIMD); the clock is not known to
+    // the probe, so every form is printed relative to v_fma_f32 at the same occupancy and in ns per wave-instruction per SIMD
+    const int occupancies[4] = {1, 2, 4, 8};
+    for (int o = 0; o < 4; ++o) {
+        g_blocks_per_cu = occupancies[o];
+        const double per_simd = 4096.0 * 16.0 * g_blocks_per_cu;        // wave-instructions issued on one SIMD
+        const float base = run(k_fma, out);
+        printf("== %d wave(s) per SIMD ==\n", g_blocks_per_cu);
+        printf("%-16s %.3f ms = 1.00  (%.3f ns per wave-instruction per SIMD)\n", "v_fma_f32", base, base * 1e6 / per_simd);
+#define SHOW(NAME) { const float t = run(k_##NAME, out); printf("%-16s %.3f ms = %.2f  (%.3f ns)\n", #NAME, t, t / base, t * 1e6 / per_simd); }
+        SHOW(fma_mix) SHOW(perm) SHOW(min_dpp) SHOW(mov_dpp) SHOW(max3) SHOW(and_or) SHOW(bcnt) SHOW(cndmask) SHOW(cmp) SHOW(lshl_add)
+        SHOW(mul_lo) SHOW(mul_u24) SHOW(bitop3) SHOW(cvt_f16) SHOW(rcp) SHOW(sqrt) SHOW(min) SHOW(div_fixup) SHOW(bpermute)
+        SHOW(fma_f64) SHOW(mul_f64) SHOW(add_f64) SHOW(rndne_f64) SHOW(ldexp_f64) SHOW(cvt_f32_f64) SHOW(cvt_f64_f32) SHOW(cvt_i32_f64)
+        SHOW(rcp_f64) SHOW(cmp_u64)
+    }
     return 0;
 }
