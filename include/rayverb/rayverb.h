@@ -65,6 +65,15 @@ inline void fixPredelay(std::vector<T> & ret, float seconds)
 // Find, then remove (reference rayverb.h:92-97).
 template <typename T>
 inline void fixPredelay(std::vector<T> & ret) { fixPredelay(ret, findPredelay(ret)); }
+// The two instantiations the reference's callers use (cmd/main.cpp:292: all channels; one channel) as library functions:
+// same results as the templates above, computed by several host threads, and applied as well to the device copies the
+// attenuators keep of the vectors they returned, so that flattenImpulses need not upload them again.
+float findPredelay(const std::vector<AttenuatedImpulse> & ret);
+float findPredelay(const std::vector<std::vector<AttenuatedImpulse>> & ret);
+void fixPredelay(std::vector<AttenuatedImpulse> & ret, float seconds);
+void fixPredelay(std::vector<std::vector<AttenuatedImpulse>> & ret, float seconds);
+void fixPredelay(std::vector<AttenuatedImpulse> & ret);
+void fixPredelay(std::vector<std::vector<AttenuatedImpulse>> & ret);
 
 // ---- device context (reference rayverb.h:99-119) ---------------------------------------------------
 
@@ -93,7 +102,7 @@ public:
 
 struct RaytracerResults {
     RaytracerResults() {}
-    RaytracerResults(const std::vector<Impulse> impulses, const cl_float3 & c) : impulses(impulses), mic(c) {}
+    RaytracerResults(std::vector<Impulse> impulses, const cl_float3 & c) : impulses(std::move(impulses)), mic(c) {}
     std::vector<Impulse> impulses;
     cl_float3 mic;
 };
@@ -113,10 +122,14 @@ public:
     RaytracerResults getRawImages(bool removeDirect);       // de-duplicated image-source contributions
     RaytracerResults getAllRaw(bool removeDirect);          // diffuse, then images
 
+    ~Raytracer();
+
 private:
     struct SceneData;
     Raytracer(unsigned long nreflections, SceneData sceneData, bool verbose);
     void upload(std::vector<Triangle> & triangles, std::vector<cl_float3> & vertices, std::vector<Surface> & surfaces);
+    void fetchDiffuse(std::vector<Impulse> & out);
+    std::vector<Impulse> mergedImages(bool removeDirect);
 
     const unsigned long nreflections;
     unsigned long nrays;

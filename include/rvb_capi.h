@@ -138,7 +138,8 @@ int rvb_attenuate_hrtf_device(rvb_ctx * ctx, const float mic[3], const void * d_
                               const float * table, const float facing[3], const float up[3], uint64_t channel, void * d_out);
 
 /* ---- time binning, materialised: replaces flattenImpulses (rayverb.cpp:48-77) for one channel.
- * Bit-exact with the reference's serial summation order.  out is [8][*nbins]. */
+ * Bit-exact with the reference's serial summation order.  out is [8][*nbins].  Called with out == NULL it reports *nbins;
+ * a following call with the same (in, n, sample_rate) finds the uploaded array and its keys still on the device. */
 int rvb_flatten(rvb_ctx * ctx, const rvb_attenuated_impulse * in, uint64_t n, float sample_rate,
                 float * out, uint64_t capacity_bins, uint64_t * nbins);
 
@@ -176,6 +177,22 @@ int rvb_ir_accumulate(rvb_ctx * ctx, float predelay, float sample_rate, uint64_t
 /* Convenience for one GPU: steps 1-3 done, histogram copied to host memory [nchannels][8][*nbins]. */
 int rvb_ir_download(rvb_ctx * ctx, int trim_predelay, float sample_rate, int mode,
                     float * out, uint64_t capacity_bins, uint64_t * nbins);
+
+/* ---- device-resident plumbing for the host mirror of the reference classes (host/rayverb_api.cpp) ------------------
+ * The reference's API hands every stage's result over as a std::vector (rayverb.h:123-133, :290-293, rayverb.cpp:28-77);
+ * its own implementation re-uploads those vectors stage by stage (rayverb.cpp:863-875).  A host that still holds the
+ * device copy of a vector it produced can skip the re-upload: these calls give it the buffers and the kernels on them. */
+int rvb_device_alloc(rvb_ctx * ctx, uint64_t bytes, void ** d_ptr);
+int rvb_device_free(rvb_ctx * ctx, void * d_ptr);
+/* Pageable host memory <-> HBM through pinned bounce buffers driven by several host threads (a plain hipMemcpy into fresh
+ * pageable memory runs at a fraction of the link rate).  Synchronous; ordered after the work already on the context's stream. */
+int rvb_copy_to_host(rvb_ctx * ctx, void * dst, const void * d_src, uint64_t bytes);
+int rvb_copy_to_device(rvb_ctx * ctx, void * d_dst, const void * src, uint64_t bytes);
+/* fixPredelay (rayverb.h:76-90) on a device-resident AttenuatedImpulse array: time = time > seconds ? time - seconds : 0. */
+int rvb_fix_predelay_device(rvb_ctx * ctx, void * d_attenuated, uint64_t n, float seconds);
+/* rvb_flatten on a device-resident AttenuatedImpulse array (same result, no upload). */
+int rvb_flatten_device(rvb_ctx * ctx, const void * d_attenuated, uint64_t n, float sample_rate,
+                       float * out, uint64_t capacity_bins, uint64_t * nbins);
 
 /* ---- measurement hooks (bench.py) ------------------------------------------------------------
  * Durations in milliseconds of the kernels of the last rvb_trace / rvb_ir_accumulate, taken with

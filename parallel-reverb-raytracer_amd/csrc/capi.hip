@@ -11,6 +11,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -76,6 +77,7 @@ struct rvb_ctx {
     std::vector<Timing> timings;
     std::vector<hipEvent_t> event_pool;
     size_t events_used = 0;
+    bool timing_failed = false;                 // an event could not be created: timings are dropped, the work itself is unaffected
 
     // impulse-response stage
     bool ir_configured = false;
@@ -85,11 +87,19 @@ struct rvb_ctx {
     uint64_t nimages = 0;
     std::vector<rvb_impulse> images_host;
 
+    // staged host copies (rvb_copy_to_host / rvb_copy_to_device): per worker thread two pinned bounce buffers and a stream
+    struct CopyLane { void * pinned[2] = {nullptr, nullptr}; hipStream_t stream = nullptr; hipEvent_t done[2] = {nullptr, nullptr}; };
+    std::vector<CopyLane> copy_lanes;
+    // rvb_flatten remembers what it uploaded for a size query, so that the fill that follows does not upload and key it again
+    const void * flat_host = nullptr;
+    uint64_t flat_n = 0, flat_bins = 0;
+    float flat_rate = 0.0f;
+
     hipEvent_t next_event()
     {
         if (events_used == event_pool.size()) {
-            hipEvent_t e;
-            (void) hipEventCreate(&e);
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) { timing_failed = true; return nullptr; }
             event_pool.push_back(e);
         }
         return event_pool[events_used++];
@@ -100,12 +110,14 @@ struct rvb_ctx {
         t.name = name;
         t.start = next_event();
         t.stop = next_event();
+        timing_open = t.start && t.stop;
+        if (!timing_open) return;
         (void) hipEventRecord(t.start, on ? on : stream);
         timings.push_back(t);
     }
-    void end_timing(hipStream_t on = nullptr) { (void) hipEventRecord(timings.back().stop, on ? on : stream); }
-    void end_timing_at(size_t index, hipStream_t on) { (void) hipEventRecord(timings[index].stop, on); }
+    void end_timing(hipStream_t on = nullptr) { if (timing_open) (void) hipEventRecord(timings.back().stop, on ? on : stream); timing_open = false; }
     void reset_timings() { timings.clear(); events_used = 0; }
+    bool timing_open = false;
 };
 
 namespace {
@@ -210,6 +222,10 @@ void rvb_destroy(rvb_ctx * ctx)
                        &ctx->keys_b, &ctx->vals_a, &ctx->vals_b, &ctx->sort_temp, &ctx->scratch_in, &ctx->scratch_out, &ctx->hist,
                        &ctx->pair_geom, &ctx->pair_direct, &ctx->pair_range})
         b->release();
+    for (rvb_ctx::CopyLane & l : ctx->copy_lanes) {
+        for (int i = 0; i < 2; ++i) { if (l.pinned[i]) (void) hipHostFree(l.pinned[i]); if (l.done[i]) (void) hipEventDestroy(l.done[i]); }
+        if (l.stream) (void) hipStreamDestroy(l.stream);
+    }
     for (hipEvent_t e : ctx->event_pool) (void) hipEventDestroy(e);
     if (ctx->path_done) (void) hipEventDestroy(ctx->path_done);
     if (ctx->side_done) (void) hipEventDestroy(ctx->side_done);
@@ -519,7 +535,7 @@ int rvb_get_diffuse(rvb_ctx * ctx, rvb_impulse * out)
     const size_t bytes = (size_t) ctx->traced_rays * ctx->nreflections * sizeof(rvb_impulse);
     if (bytes) {
         if (!out) return fail(ctx, RVB_ERR_INVALID, "rvb_get_diffuse: null output");
-        RVB_HIP(ctx, hipMemcpy(out, ctx->impulses.p, bytes, hipMemcpyDeviceToHost));
+        return rvb_copy_to_host(ctx, out, ctx->impulses.p, bytes);
     }
     return RVB_OK;
 }
@@ -638,15 +654,14 @@ static int run_attenuate(rvb_ctx * ctx, const AttenuationModel & m, uint32_t cha
     if (!in || !out) return fail(ctx, RVB_ERR_INVALID, "attenuate: null buffer");
     RVB_HIP(ctx, ctx->scratch_in.ensure(n * sizeof(rvb_impulse)));
     RVB_HIP(ctx, ctx->scratch_out.ensure(n * sizeof(rvb_attenuated_impulse)));
-    RVB_HIP(ctx, hipMemcpyAsync(ctx->scratch_in.p, in, n * sizeof(rvb_impulse), hipMemcpyHostToDevice, ctx->stream));
+    int rc = rvb_copy_to_device(ctx, ctx->scratch_in.p, in, n * sizeof(rvb_impulse));
+    if (rc != RVB_OK) return rc;
     ctx->reset_timings();
     ctx->begin_timing("attenuate_kernel");
     rvb_launch_attenuate(m, channel, ctx->scratch_in.as<rvb_impulse>(), n, ctx->scratch_out.as<rvb_attenuated_impulse>(), ctx->stream);
     ctx->end_timing();
     RVB_HIP(ctx, hipGetLastError());
-    RVB_HIP(ctx, hipMemcpyAsync(out, ctx->scratch_out.p, n * sizeof(rvb_attenuated_impulse), hipMemcpyDeviceToHost, ctx->stream));
-    RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return RVB_OK;
+    return rvb_copy_to_host(ctx, out, ctx->scratch_out.p, n * sizeof(rvb_attenuated_impulse));
 }
 
 int rvb_attenuate_speaker(rvb_ctx * ctx, const float mic[3], const rvb_impulse * in, uint64_t n,
@@ -743,6 +758,35 @@ static int ensure_sort_buffers(rvb_ctx * ctx, uint64_t n)
     return RVB_OK;
 }
 
+// keys + max time of a device-resident AttenuatedImpulse array -> *bins; then (out != NULL) sort, ordered sum, download
+static int flatten_keys(rvb_ctx * ctx, const rvb_attenuated_impulse * d_in, uint64_t n, float sample_rate, uint64_t * bins)
+{
+    int rc = ensure_sort_buffers(ctx, n);
+    if (rc != RVB_OK) return rc;
+    uint32_t * max_bits = reinterpret_cast<uint32_t *>(ctx->small.as<char>() + kSmallMaxTime);
+    RVB_HIP(ctx, hipMemsetAsync(max_bits, 0, 4, ctx->stream));
+    rvb_launch_flat_keys(d_in, n, sample_rate, ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), max_bits, ctx->stream);
+    uint32_t bits = 0;
+    RVB_HIP(ctx, hipMemcpyAsync(&bits, max_bits, 4, hipMemcpyDeviceToHost, ctx->stream));
+    RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    float max_time;
+    std::memcpy(&max_time, &bits, 4);
+    *bins = bins_for(max_time, 0.0f, sample_rate);
+    return RVB_OK;
+}
+
+static int flatten_sum(rvb_ctx * ctx, const rvb_attenuated_impulse * d_in, uint64_t n, uint64_t bins, float * out)
+{
+    RVB_HIP(ctx, ctx->hist.ensure(bins * 8 * sizeof(float)));
+    rvb_sort_pairs(ctx->sort_temp.p, ctx->sort_temp.cap, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(),
+                   ctx->vals_a.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), n, key_bits_for(bins), ctx->stream);
+    rvb_launch_flat_ordered_sum(d_in, ctx->keys_b.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), n, bins, ctx->hist.as<float>(), ctx->stream);
+    RVB_HIP(ctx, hipGetLastError());
+    RVB_HIP(ctx, hipMemcpyAsync(out, ctx->hist.p, bins * 8 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RVB_OK;
+}
+
 int rvb_flatten(rvb_ctx * ctx, const rvb_attenuated_impulse * in, uint64_t n, float sample_rate,
                 float * out, uint64_t capacity_bins, uint64_t * nbins)
 {
@@ -750,34 +794,185 @@ int rvb_flatten(rvb_ctx * ctx, const rvb_attenuated_impulse * in, uint64_t n, fl
     if (n && !in) return fail(ctx, RVB_ERR_INVALID, "rvb_flatten: null input");
     if (n >= (1ull << 32)) return fail(ctx, RVB_ERR_CAPACITY, "rvb_flatten: too many impulses");
     RVB_BIND(ctx);
-    RVB_HIP(ctx, ctx->scratch_in.ensure(n * sizeof(rvb_attenuated_impulse)));
-    int rc = ensure_sort_buffers(ctx, n);
+    // the fill that follows a size query of the same array finds it (and its keys) on the device
+    const bool resident = out && ctx->flat_host == in && ctx->flat_n == n && ctx->flat_rate == sample_rate && in != nullptr;
+    uint64_t bins = ctx->flat_bins;
+    if (!resident) {
+        ctx->flat_host = nullptr;
+        RVB_HIP(ctx, ctx->scratch_in.ensure(n * sizeof(rvb_attenuated_impulse)));
+        if (n) {
+            int rc = rvb_copy_to_device(ctx, ctx->scratch_in.p, in, n * sizeof(rvb_attenuated_impulse));
+            if (rc != RVB_OK) return rc;
+        }
+        int rc = flatten_keys(ctx, ctx->scratch_in.as<rvb_attenuated_impulse>(), n, sample_rate, &bins);
+        if (rc != RVB_OK) return rc;
+    }
+    *nbins = bins;
+    if (!out) {
+        ctx->flat_host = in; ctx->flat_n = n; ctx->flat_rate = sample_rate; ctx->flat_bins = bins;
+        return RVB_OK;
+    }
+    ctx->flat_host = nullptr;                 // (the sort consumes the keys)
+    if (capacity_bins < bins)
+        return fail(ctx, RVB_ERR_CAPACITY, "rvb_flatten: capacity_bins too small");
+    return flatten_sum(ctx, ctx->scratch_in.as<rvb_attenuated_impulse>(), n, bins, out);
+}
+
+int rvb_flatten_device(rvb_ctx * ctx, const void * d_attenuated, uint64_t n, float sample_rate,
+                       float * out, uint64_t capacity_bins, uint64_t * nbins)
+{
+    if (!ctx || !nbins) return RVB_ERR_INVALID;
+    if (n && !d_attenuated) return fail(ctx, RVB_ERR_INVALID, "rvb_flatten_device: null input");
+    if (n >= (1ull << 32)) return fail(ctx, RVB_ERR_CAPACITY, "rvb_flatten_device: too many impulses");
+    RVB_BIND(ctx);
+    ctx->flat_host = nullptr;
+    uint64_t bins = 0;
+    int rc = flatten_keys(ctx, reinterpret_cast<const rvb_attenuated_impulse *>(d_attenuated), n, sample_rate, &bins);
     if (rc != RVB_OK) return rc;
-    uint32_t * max_bits = reinterpret_cast<uint32_t *>(ctx->small.as<char>() + kSmallMaxTime);
-    RVB_HIP(ctx, hipMemsetAsync(max_bits, 0, 4, ctx->stream));
-    if (n) RVB_HIP(ctx, hipMemcpyAsync(ctx->scratch_in.p, in, n * sizeof(rvb_attenuated_impulse), hipMemcpyHostToDevice, ctx->stream));
-    rvb_launch_flat_keys(ctx->scratch_in.as<rvb_attenuated_impulse>(), n, sample_rate, ctx->keys_a.as<uint32_t>(),
-                         ctx->vals_a.as<uint32_t>(), max_bits, ctx->stream);
-    uint32_t bits = 0;
-    RVB_HIP(ctx, hipMemcpyAsync(&bits, max_bits, 4, hipMemcpyDeviceToHost, ctx->stream));
-    RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    float max_time;
-    std::memcpy(&max_time, &bits, 4);
-    const uint64_t bins = bins_for(max_time, 0.0f, sample_rate);
     *nbins = bins;
     if (!out)
         return RVB_OK;
     if (capacity_bins < bins)
-        return fail(ctx, RVB_ERR_CAPACITY, "rvb_flatten: capacity_bins too small");
-    RVB_HIP(ctx, ctx->hist.ensure(bins * 8 * sizeof(float)));
-    rvb_sort_pairs(ctx->sort_temp.p, ctx->sort_temp.cap, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(),
-                   ctx->vals_a.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), n, key_bits_for(bins), ctx->stream);
-    rvb_launch_flat_ordered_sum(ctx->scratch_in.as<rvb_attenuated_impulse>(), ctx->keys_b.as<uint32_t>(), ctx->vals_b.as<uint32_t>(),
-                                n, bins, ctx->hist.as<float>(), ctx->stream);
+        return fail(ctx, RVB_ERR_CAPACITY, "rvb_flatten_device: capacity_bins too small");
+    return flatten_sum(ctx, reinterpret_cast<const rvb_attenuated_impulse *>(d_attenuated), n, bins, out);
+}
+
+int rvb_fix_predelay_device(rvb_ctx * ctx, void * d_attenuated, uint64_t n, float seconds)
+{
+    if (!ctx) return RVB_ERR_INVALID;
+    if (n && !d_attenuated) return fail(ctx, RVB_ERR_INVALID, "rvb_fix_predelay_device: null array");
+    RVB_BIND(ctx);
+    rvb_launch_fix_predelay(reinterpret_cast<rvb_attenuated_impulse *>(d_attenuated), n, seconds, ctx->stream);
     RVB_HIP(ctx, hipGetLastError());
-    RVB_HIP(ctx, hipMemcpyAsync(out, ctx->hist.p, bins * 8 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RVB_OK;
+}
+
+// ---- device buffers and staged host copies ----------------------------------------------------------
+
+int rvb_device_alloc(rvb_ctx * ctx, uint64_t bytes, void ** d_ptr)
+{
+    if (!ctx || !d_ptr) return RVB_ERR_INVALID;
+    RVB_BIND(ctx);
+    *d_ptr = nullptr;
+    RVB_HIP(ctx, hipMalloc(d_ptr, bytes ? bytes : 16));
+    return RVB_OK;
+}
+
+int rvb_device_free(rvb_ctx * ctx, void * d_ptr)
+{
+    if (!ctx) return RVB_ERR_INVALID;
+    if (!d_ptr) return RVB_OK;
+    RVB_BIND(ctx);
+    RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RVB_HIP(ctx, hipFree(d_ptr));
+    return RVB_OK;
+}
+
+namespace {
+
+const size_t kCopyChunk = 8u << 20;          // bytes per pinned bounce buffer
+
+int copy_lane_count()
+{
+    static const int lanes = [] {
+        if (const char * e = getenv("RVB_COPY_THREADS")) return std::max(1, std::min(32, atoi(e)));
+        const unsigned hw = std::thread::hardware_concurrency();
+        return (int) std::max(1u, std::min(8u, hw ? hw / 2 : 4u));
+    }();
+    return lanes;
+}
+
+hipError_t ensure_copy_lanes(rvb_ctx * ctx)
+{
+    if (!ctx->copy_lanes.empty()) return hipSuccess;
+    std::vector<rvb_ctx::CopyLane> lanes((size_t) copy_lane_count());
+    for (rvb_ctx::CopyLane & l : lanes) {
+        hipError_t e;
+        for (int i = 0; i < 2; ++i) {
+            if ((e = hipHostMalloc(&l.pinned[i], kCopyChunk, hipHostMallocDefault)) != hipSuccess) return e;
+            if ((e = hipEventCreateWithFlags(&l.done[i], hipEventDisableTiming)) != hipSuccess) return e;
+        }
+        if ((e = hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking)) != hipSuccess) return e;
+    }
+    ctx->copy_lanes.swap(lanes);
+    return hipSuccess;
+}
+
+// One lane's slice: chunk k+1 is on the link while chunk k is copied between the bounce buffer and pageable memory.
+hipError_t lane_copy(int device, rvb_ctx::CopyLane & l, char * host, char * dev, size_t bytes, bool to_host)
+{
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return e;
+    const size_t nchunks = (bytes + kCopyChunk - 1) / kCopyChunk;
+    auto span = [&](size_t k) { return std::min(kCopyChunk, bytes - k * kCopyChunk); };
+    if (to_host) {
+        if (nchunks && (e = hipMemcpyAsync(l.pinned[0], dev, span(0), hipMemcpyDeviceToHost, l.stream)) != hipSuccess) return e;
+        if (nchunks && (e = hipEventRecord(l.done[0], l.stream)) != hipSuccess) return e;
+        for (size_t k = 0; k < nchunks; ++k) {
+            if (k + 1 < nchunks) {
+                if ((e = hipMemcpyAsync(l.pinned[(k + 1) & 1], dev + (k + 1) * kCopyChunk, span(k + 1), hipMemcpyDeviceToHost, l.stream)) != hipSuccess) return e;
+                if ((e = hipEventRecord(l.done[(k + 1) & 1], l.stream)) != hipSuccess) return e;
+            }
+            if ((e = hipEventSynchronize(l.done[k & 1])) != hipSuccess) return e;
+            std::memcpy(host + k * kCopyChunk, l.pinned[k & 1], span(k));
+        }
+    } else {
+        for (size_t k = 0; k < nchunks; ++k) {
+            if (k >= 2 && (e = hipEventSynchronize(l.done[k & 1])) != hipSuccess) return e;      // the buffer's previous chunk has left
+            std::memcpy(l.pinned[k & 1], host + k * kCopyChunk, span(k));
+            if ((e = hipMemcpyAsync(dev + k * kCopyChunk, l.pinned[k & 1], span(k), hipMemcpyHostToDevice, l.stream)) != hipSuccess) return e;
+            if ((e = hipEventRecord(l.done[k & 1], l.stream)) != hipSuccess) return e;
+        }
+        if ((e = hipStreamSynchronize(l.stream)) != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+int staged_copy(rvb_ctx * ctx, void * host, void * dev, uint64_t bytes, bool to_host)
+{
+    if (bytes == 0) return RVB_OK;
+    RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));          // ordered after the context's work
+    if (bytes < (4u << 20)) {                                 // small: one plain copy
+        RVB_HIP(ctx, to_host ? hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost) : hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice));
+        return RVB_OK;
+    }
+    RVB_HIP(ctx, ensure_copy_lanes(ctx));
+    const size_t lanes = ctx->copy_lanes.size();
+    // slices are multiples of the chunk so that every lane moves whole chunks (2 MiB-aligned destinations keep the page
+    // faults of fresh memory apart)
+    const size_t chunks = (bytes + kCopyChunk - 1) / kCopyChunk, per = (chunks + lanes - 1) / lanes;
+    std::vector<hipError_t> status(lanes, hipSuccess);
+    std::vector<std::thread> workers;
+    for (size_t i = 0; i < lanes; ++i) {
+        const size_t first = i * per * kCopyChunk;
+        if (first >= bytes) break;
+        const size_t len = std::min((size_t) bytes - first, per * kCopyChunk);
+        workers.emplace_back([=, &status] {
+            status[i] = lane_copy(ctx->device, ctx->copy_lanes[i], static_cast<char *>(host) + first, static_cast<char *>(dev) + first, len, to_host);
+        });
+    }
+    for (std::thread & t : workers) t.join();
+    for (hipError_t e : status)
+        if (e != hipSuccess) return fail(ctx, RVB_ERR_HIP, std::string("staged copy: ") + hipGetErrorString(e));
+    return RVB_OK;
+}
+
+}  // namespace
+
+int rvb_copy_to_host(rvb_ctx * ctx, void * dst, const void * d_src, uint64_t bytes)
+{
+    if (!ctx) return RVB_ERR_INVALID;
+    if (bytes && (!dst || !d_src)) return fail(ctx, RVB_ERR_INVALID, "rvb_copy_to_host: null pointer");
+    RVB_BIND(ctx);
+    return staged_copy(ctx, dst, const_cast<void *>(d_src), bytes, true);
+}
+
+int rvb_copy_to_device(rvb_ctx * ctx, void * d_dst, const void * src, uint64_t bytes)
+{
+    if (!ctx) return RVB_ERR_INVALID;
+    if (bytes && (!d_dst || !src)) return fail(ctx, RVB_ERR_INVALID, "rvb_copy_to_device: null pointer");
+    RVB_BIND(ctx);
+    return staged_copy(ctx, const_cast<void *>(src), d_dst, bytes, false);
 }
 
 // ---- fused impulse-response stage ----------------------------------------------------------------

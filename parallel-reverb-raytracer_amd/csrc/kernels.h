@@ -100,6 +100,7 @@ void rvb_launch_flat_keys(const rvb_attenuated_impulse * in, uint64_t n, float s
                           uint32_t * max_time_bits, hipStream_t s);
 void rvb_launch_flat_ordered_sum(const rvb_attenuated_impulse * in, const uint32_t * sorted_keys, const uint32_t * sorted_values,
                                  uint64_t n, uint64_t nbins, float * out, hipStream_t s);
+void rvb_launch_fix_predelay(rvb_attenuated_impulse * a, uint64_t n, float seconds, hipStream_t s);
 // stable sort of (key, value) pairs by key (device radix sort); temp storage managed by the caller
 size_t rvb_sort_temp_bytes(uint64_t n);
 void rvb_sort_pairs(void * temp, size_t temp_bytes, const uint32_t * keys_in, uint32_t * keys_out,

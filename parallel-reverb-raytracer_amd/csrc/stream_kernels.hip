@@ -501,6 +501,15 @@ __global__ __launch_bounds__(256) void flat_keys_kernel(const rvb_attenuated_imp
         atomicMax(max_time_bits, __float_as_uint(tmax));     // only a wave that can still raise the maximum pays for the atomic
 }
 
+// fixPredelay (rayverb.h:76-90) on a resident AttenuatedImpulse array: the time is the first float of the third 16-byte chunk
+__global__ __launch_bounds__(256) void fix_predelay_kernel(rvb_attenuated_impulse * __restrict__ a, uint64_t n, float seconds)
+{
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+        const float t = a[i].time;
+        a[i].time = t > seconds ? t - seconds : 0.0f;
+    }
+}
+
 __global__ __launch_bounds__(64) void flat_ordered_sum_kernel(const rvb_attenuated_impulse * __restrict__ in,
                                                               const uint32_t * __restrict__ keys, const uint32_t * __restrict__ values,
                                                               uint64_t n, uint64_t nbins, float * __restrict__ out)
@@ -607,6 +616,12 @@ void rvb_launch_flat_keys(const rvb_attenuated_impulse * in, uint64_t n, float s
 {
     if (n == 0) return;
     hipLaunchKernelGGL(flat_keys_kernel, dim3(stream_blocks(n, 256)), dim3(256), 0, s, in, n, sample_rate, keys, values, max_time_bits);
+}
+
+void rvb_launch_fix_predelay(rvb_attenuated_impulse * a, uint64_t n, float seconds, hipStream_t s)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(fix_predelay_kernel, dim3(stream_blocks(n, 256)), dim3(256), 0, s, a, n, seconds);
 }
 
 void rvb_launch_flat_ordered_sum(const rvb_attenuated_impulse * in, const uint32_t * sorted_keys, const uint32_t * sorted_values,

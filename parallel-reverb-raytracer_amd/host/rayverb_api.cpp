@@ -9,7 +9,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <list>
 #include <mutex>
+#include <thread>
 
 static_assert(sizeof(Triangle) == sizeof(rvb_triangle), "Triangle");
 static_assert(sizeof(cl_float3) == sizeof(rvb_float3), "cl_float3");
@@ -42,6 +44,144 @@ rvb_ctx * shared_context()
     return ctx.get();
 }
 
+// A std::vector of n elements whose storage is NOT value-initialised: the vectors this API returns hold up to a gigabyte that
+// the next line overwrites from the device, and std::vector<T>(n) would first zero-fill it on one core (0.1-0.15 s per
+// 819 MB vector).  libstdc++ only (the size is set through the vector base's own pointers); any other standard library gets
+// the ordinary zero-filled vector.
+template <class T>
+std::vector<T> uninitialized_vector(size_t n)
+{
+#if defined(__GLIBCXX__) && !defined(_GLIBCXX_DEBUG) && !defined(RVB_SAFE_VECTORS)
+    struct Access : std::vector<T> {
+        void adopt(size_t count) { this->_M_impl._M_finish = this->_M_impl._M_start + count; }
+    };
+    static_assert(sizeof(Access) == sizeof(std::vector<T>), "no state of its own");
+    std::vector<T> v;
+    v.reserve(n);
+    static_cast<Access &>(v).adopt(n);         // T is a POD of this library (Impulse, AttenuatedImpulse)
+    return v;
+#else
+    return std::vector<T>(n);
+#endif
+}
+
+unsigned host_threads()
+{
+    static const unsigned n = [] {
+        if (const char * e = std::getenv("RVB_HOST_THREADS")) return (unsigned) std::max(1, std::atoi(e));
+        const unsigned hw = std::thread::hardware_concurrency();
+        return std::max(1u, std::min(8u, hw ? hw / 2 : 4u));
+    }();
+    return n;
+}
+
+// f(first, last) over [0, n) on several threads
+template <class F>
+void parallel_ranges(size_t n, F f)
+{
+    const size_t threads = n < (1u << 16) ? 1 : host_threads();
+    if (threads <= 1) { f((size_t) 0, n); return; }
+    std::vector<std::thread> pool;
+    const size_t per = (n + threads - 1) / threads;
+    for (size_t t = 0; t < threads; ++t) {
+        const size_t lo = t * per, hi = std::min(n, lo + per);
+        if (lo >= hi) break;
+        pool.emplace_back([=] { f(lo, hi); });
+    }
+    for (std::thread & t : pool) t.join();
+}
+
+// ---- device copies of vectors this library handed out ------------------------------------------------------------------
+// The reference's API moves every stage's result through std::vector; its implementation re-uploads them stage by stage
+// (rayverb.cpp:863-875).  Here the producer of a vector remembers where its device copy lives, keyed by the vector's buffer
+// (address, element count), and the next stage uses that copy when it is handed the same buffer: Raytracer::getAllRaw ->
+// Attenuator::attenuate, attenuate -> fixPredelay -> flattenImpulses (the sequence of cmd/main.cpp:241-298).
+// A caller may have changed the vector in between.  Its length or address changing is caught by the key; an in-place edit is
+// caught by comparing a sample (every kSampleStride-th element, taken when the entry was made or last updated by this
+// library) — an edit confined to elements outside the sample is NOT seen; RVB_API_RESIDENT=0 turns the whole mechanism off.
+const size_t kSampleStride = 251;
+
+struct Resident {
+    const void * host = nullptr;      // the vector's buffer
+    size_t count = 0, elem = 0;       // elements, bytes per element
+    void * device = nullptr;          // device copy (of `device_count` leading elements)
+    size_t device_count = 0;
+    bool owned = false;               // allocated for this entry (freed with it) / borrowed from a Raytracer's context
+    const void * owner = nullptr;     // the Raytracer whose trace buffer is borrowed
+    std::vector<unsigned char> sample;
+};
+
+std::mutex g_resident_mutex;
+std::list<Resident> g_resident;
+
+bool resident_enabled()
+{
+    static const bool on = !(std::getenv("RVB_API_RESIDENT") && std::getenv("RVB_API_RESIDENT")[0] == '0');
+    return on;
+}
+
+std::vector<unsigned char> take_sample(const void * host, size_t count, size_t elem)
+{
+    std::vector<unsigned char> s;
+    s.reserve((count / kSampleStride + 2) * elem);
+    const unsigned char * p = static_cast<const unsigned char *>(host);
+    for (size_t i = 0; i < count; i += kSampleStride) s.insert(s.end(), p + i * elem, p + (i + 1) * elem);
+    if (count) s.insert(s.end(), p + (count - 1) * elem, p + count * elem);
+    return s;
+}
+
+void release_entry(Resident & r)
+{
+    if (r.owned && r.device) (void) rvb_device_free(shared_context(), r.device);
+    r.device = nullptr;
+}
+
+void resident_forget_owner(const void * owner)
+{
+    std::lock_guard<std::mutex> lock(g_resident_mutex);
+    for (auto it = g_resident.begin(); it != g_resident.end();)
+        if (it->owner == owner) { release_entry(*it); it = g_resident.erase(it); } else ++it;
+}
+
+void resident_remember(Resident r)
+{
+    if (!resident_enabled()) { release_entry(r); return; }
+    r.sample = take_sample(r.host, r.count, r.elem);
+    std::lock_guard<std::mutex> lock(g_resident_mutex);
+    for (auto it = g_resident.begin(); it != g_resident.end();)      // a buffer address names one vector at a time
+        if (it->host == r.host) { release_entry(*it); it = g_resident.erase(it); } else ++it;
+    g_resident.push_front(std::move(r));
+    while (g_resident.size() > 24) { release_entry(g_resident.back()); g_resident.pop_back(); }
+}
+
+// the entry of (host, count) if the vector still reads as it did; stale entries are dropped
+bool resident_find(const void * host, size_t count, size_t elem, Resident & out)
+{
+    if (!resident_enabled() || !host) return false;
+    std::lock_guard<std::mutex> lock(g_resident_mutex);
+    for (auto it = g_resident.begin(); it != g_resident.end(); ++it) {
+        if (it->host != host) continue;
+        if (it->count == count && it->elem == elem && it->sample == take_sample(host, count, elem)) { out = *it; out.sample.clear(); return true; }
+        release_entry(*it);
+        g_resident.erase(it);
+        return false;
+    }
+    return false;
+}
+
+void resident_resample(const void * host, size_t count, size_t elem)
+{
+    std::lock_guard<std::mutex> lock(g_resident_mutex);
+    for (Resident & r : g_resident)
+        if (r.host == host && r.count == count && r.elem == elem) r.sample = take_sample(host, count, elem);
+}
+
+void throw_on(int rc, rvb_ctx * ctx, const char * where)
+{
+    if (rc != RVB_OK)
+        throw cl::Error(rc, (std::string(where) + ": " + rvb_last_error(ctx)).c_str());
+}
+
 }  // namespace
 
 // ---- context -------------------------------------------------------------------------------------
@@ -68,20 +208,26 @@ KernelLoader::KernelLoader(bool verbose)
     }
 }
 
-// ---- time binning ----------------------------------------------------------------------------------
+// ---- time binning and predelay -------------------------------------------------------------------------
 
 std::vector<std::vector<float>> flattenImpulses(const std::vector<AttenuatedImpulse> & impulse, float samplerate)
 {
     rvb_ctx * ctx = shared_context();
-    const rvb_attenuated_impulse * in = reinterpret_cast<const rvb_attenuated_impulse *>(impulse.data());
     uint64_t nbins = 0;
-    int rc = rvb_flatten(ctx, in, impulse.size(), samplerate, nullptr, 0, &nbins);
-    if (rc != RVB_OK)
-        throw cl::Error(rc, rvb_last_error(ctx));
-    std::vector<float> flat(8 * nbins);
-    rc = rvb_flatten(ctx, in, impulse.size(), samplerate, flat.data(), nbins, &nbins);
-    if (rc != RVB_OK)
-        throw cl::Error(rc, rvb_last_error(ctx));
+    std::vector<float> flat;
+    Resident r;
+    if (resident_find(impulse.data(), impulse.size(), sizeof(AttenuatedImpulse), r) && r.device_count == impulse.size()) {
+        // the attenuator's device copy (kept in step by fixPredelay): no upload
+        throw_on(rvb_flatten_device(ctx, r.device, impulse.size(), samplerate, nullptr, 0, &nbins), ctx, "rvb_flatten_device");
+        flat.resize(8 * nbins);
+        // (the size query left the keys on the device; the second call redoes only them, not an upload)
+        throw_on(rvb_flatten_device(ctx, r.device, impulse.size(), samplerate, flat.data(), nbins, &nbins), ctx, "rvb_flatten_device");
+    } else {
+        const rvb_attenuated_impulse * in = reinterpret_cast<const rvb_attenuated_impulse *>(impulse.data());
+        throw_on(rvb_flatten(ctx, in, impulse.size(), samplerate, nullptr, 0, &nbins), ctx, "rvb_flatten");      // uploads once ...
+        flat.resize(8 * nbins);
+        throw_on(rvb_flatten(ctx, in, impulse.size(), samplerate, flat.data(), nbins, &nbins), ctx, "rvb_flatten");   // ... and fills from the device copy
+    }
     std::vector<std::vector<float>> flattened(sizeof(VolumeType) / sizeof(float));
     for (size_t b = 0; b < flattened.size(); ++b)
         flattened[b].assign(flat.begin() + (long) (b * nbins), flat.begin() + (long) ((b + 1) * nbins));
@@ -95,6 +241,68 @@ std::vector<std::vector<std::vector<float>>> flattenImpulses(const std::vector<s
         flattened[i] = flattenImpulses(attenuated[i], samplerate);
     return flattened;
 }
+
+// reference rayverb.h:49-74: the smallest non-zero time, 0 if there is none (min is order-independent: threads may split the range)
+float findPredelay(const std::vector<AttenuatedImpulse> & ret)
+{
+    const size_t n = ret.size();
+    const size_t threads = n < (1u << 16) ? 1 : host_threads();
+    std::vector<float> part(threads, 0.0f);
+    const size_t per = threads ? (n + threads - 1) / threads : 0;
+    std::vector<std::thread> pool;
+    auto work = [&](size_t t) {
+        float a = 0.0f;
+        for (size_t i = t * per; i < std::min(n, (t + 1) * per); ++i) {
+            const float pd = ret[i].time;
+            if (pd != 0.0f && (a == 0.0f || pd < a)) a = pd;
+        }
+        part[t] = a;
+    };
+    if (threads <= 1) { if (threads) work(0); }
+    else {
+        for (size_t t = 0; t < threads; ++t) pool.emplace_back(work, t);
+        for (std::thread & t : pool) t.join();
+    }
+    float a = 0.0f;
+    for (float pd : part)
+        if (pd != 0.0f && (a == 0.0f || pd < a)) a = pd;
+    return a;
+}
+
+float findPredelay(const std::vector<std::vector<AttenuatedImpulse>> & ret)
+{
+    float a = 0.0f;
+    for (const std::vector<AttenuatedImpulse> & channel : ret) {
+        const float pd = findPredelay(channel);
+        if (pd != 0.0f && (a == 0.0f || pd < a)) a = pd;
+    }
+    return a;
+}
+
+// reference rayverb.h:76-90, on the host vector and on its device copy if there is one
+void fixPredelay(std::vector<AttenuatedImpulse> & ret, float seconds)
+{
+    // the device copy takes part only if the vector still reads as it did when the copy was made (sample comparison)
+    Resident r;
+    const bool have = resident_find(ret.data(), ret.size(), sizeof(AttenuatedImpulse), r) && r.owned && r.device_count == ret.size();
+    AttenuatedImpulse * a = ret.data();
+    parallel_ranges(ret.size(), [a, seconds](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) a[i].time = a[i].time > seconds ? a[i].time - seconds : 0;
+    });
+    if (!have) return;
+    rvb_ctx * ctx = shared_context();
+    throw_on(rvb_fix_predelay_device(ctx, r.device, r.device_count, seconds), ctx, "rvb_fix_predelay_device");
+    resident_resample(ret.data(), ret.size(), sizeof(AttenuatedImpulse));
+}
+
+void fixPredelay(std::vector<std::vector<AttenuatedImpulse>> & ret, float seconds)
+{
+    for (std::vector<AttenuatedImpulse> & channel : ret)
+        fixPredelay(channel, seconds);
+}
+
+void fixPredelay(std::vector<AttenuatedImpulse> & ret) { fixPredelay(ret, findPredelay(ret)); }
+void fixPredelay(std::vector<std::vector<AttenuatedImpulse>> & ret) { fixPredelay(ret, findPredelay(ret)); }
 
 // ---- ray tracer ------------------------------------------------------------------------------------
 
@@ -157,9 +365,15 @@ void Raytracer::upload(std::vector<Triangle> & triangles, std::vector<cl_float3>
           "rvb_set_scene");
 }
 
+Raytracer::~Raytracer()
+{
+    resident_forget_owner(this);               // entries that borrow this tracer's trace buffer
+}
+
 void Raytracer::raytrace(const cl_float3 & micpos, const cl_float3 & source, const std::vector<cl_float3> & directions, bool verbose)
 {
     storedMicpos = micpos;
+    resident_forget_owner(this);               // the trace buffer is about to be overwritten
 
     // reference rayverb.cpp:547-583: warn when mic or source lie outside the model's bounding box
     const bool micinside = inside(bounds, micpos);
@@ -186,14 +400,22 @@ void Raytracer::raytrace(const cl_float3 & micpos, const cl_float3 & source, con
     check(rvb_synchronize(context()), "rvb_synchronize");     // the reference's raytrace() is blocking
 }
 
-RaytracerResults Raytracer::getRawDiffuse()
+// diffuse impulses into out[0 .. nrays * nreflections), and the note that this buffer has a device copy
+void Raytracer::fetchDiffuse(std::vector<Impulse> & out)
 {
-    std::vector<Impulse> diffuse(nrays * nreflections);
-    check(rvb_get_diffuse(context(), reinterpret_cast<rvb_impulse *>(diffuse.data())), "rvb_get_diffuse");
-    return RaytracerResults(diffuse, storedMicpos);
+    const size_t n = nrays * nreflections;
+    check(rvb_get_diffuse(context(), reinterpret_cast<rvb_impulse *>(out.data())), "rvb_get_diffuse");
+    const void * d = nullptr;
+    uint64_t count = 0;
+    if (n && rvb_diffuse_device(context(), &d, &count) == RVB_OK && count == n) {
+        Resident r;
+        r.host = out.data(); r.count = out.size(); r.elem = sizeof(Impulse);
+        r.device = const_cast<void *>(d); r.device_count = n; r.owned = false; r.owner = this;
+        resident_remember(r);
+    }
 }
 
-RaytracerResults Raytracer::getRawImages(bool removeDirect)
+std::vector<Impulse> Raytracer::mergedImages(bool removeDirect)
 {
     uint64_t ncand = 0;
     check(rvb_get_image_candidates(context(), nullptr, 0, &ncand), "rvb_get_image_candidates");
@@ -207,15 +429,30 @@ RaytracerResults Raytracer::getRawImages(bool removeDirect)
     std::vector<Impulse> ret(count);
     check(rvb_merge_images(cand.data(), cand.size(), direct_ptr, removeDirect, reinterpret_cast<rvb_impulse *>(ret.data()), count, &count),
           "rvb_merge_images");
-    return RaytracerResults(ret, storedMicpos);
+    return ret;
+}
+
+RaytracerResults Raytracer::getRawDiffuse()
+{
+    std::vector<Impulse> diffuse = uninitialized_vector<Impulse>(nrays * nreflections);
+    fetchDiffuse(diffuse);
+    return RaytracerResults(std::move(diffuse), storedMicpos);
+}
+
+RaytracerResults Raytracer::getRawImages(bool removeDirect)
+{
+    return RaytracerResults(mergedImages(removeDirect), storedMicpos);
 }
 
 RaytracerResults Raytracer::getAllRaw(bool removeDirect)
 {
-    std::vector<Impulse> diffuse = getRawDiffuse().impulses;
-    const std::vector<Impulse> image = getRawImages(removeDirect).impulses;
-    diffuse.insert(diffuse.end(), image.begin(), image.end());
-    return RaytracerResults(diffuse, storedMicpos);
+    // diffuse, then images (reference rayverb.cpp:708-714) — built in one buffer, no intermediate vectors
+    const std::vector<Impulse> image = mergedImages(removeDirect);
+    const size_t nd = nrays * nreflections;
+    std::vector<Impulse> all = uninitialized_vector<Impulse>(nd + image.size());
+    std::copy(image.begin(), image.end(), all.begin() + (long) nd);
+    fetchDiffuse(all);
+    return RaytracerResults(std::move(all), storedMicpos);
 }
 
 // ---- attenuators -------------------------------------------------------------------------------------
@@ -262,18 +499,95 @@ std::vector<std::vector<AttenuatedImpulse>> HrtfAttenuator::attenuate(const Rayt
     return attenuate(results, config.facing, config.up);
 }
 
+// The impulses of `results` on the shared context's device: the trace buffer they were downloaded from when the vector is
+// the one getAllRaw / getRawDiffuse returned (plus the few image impulses behind it), else an upload.
+namespace {
+struct DeviceImpulses {
+    explicit DeviceImpulses(rvb_ctx * c) : ctx(c) {}
+    DeviceImpulses(const DeviceImpulses &) = delete;
+    DeviceImpulses & operator=(const DeviceImpulses &) = delete;
+    rvb_ctx * ctx;
+    const void * head = nullptr;      // first `nhead` impulses (a Raytracer's trace buffer, borrowed, or the whole upload)
+    size_t nhead = 0;
+    void * tail = nullptr;            // the rest (uploaded; owned)
+    size_t ntail = 0;
+    void * upload = nullptr;          // owned storage behind `head` when nothing was resident
+    ~DeviceImpulses()
+    {
+        if (tail) (void) rvb_device_free(ctx, tail);
+        if (upload) (void) rvb_device_free(ctx, upload);
+    }
+};
+
+void stage_impulses(const std::vector<Impulse> & impulses, DeviceImpulses & dev)
+{
+    rvb_ctx * ctx = dev.ctx;
+    const size_t n = impulses.size();
+    Resident r;
+    if (resident_find(impulses.data(), n, sizeof(Impulse), r) && !r.owned && r.device_count <= n) {
+        // getRawDiffuse / getAllRaw: the diffuse impulses are still in the tracer's buffer; the few image impulses that
+        // getAllRaw put behind them come from the host vector
+        dev.head = r.device;
+        dev.nhead = r.device_count;
+        dev.ntail = n - r.device_count;
+        if (dev.ntail) {
+            throw_on(rvb_device_alloc(ctx, dev.ntail * sizeof(Impulse), &dev.tail), ctx, "rvb_device_alloc");
+            throw_on(rvb_copy_to_device(ctx, dev.tail, impulses.data() + dev.nhead, dev.ntail * sizeof(Impulse)), ctx, "rvb_copy_to_device");
+        }
+        return;
+    }
+    if (n == 0) return;
+    throw_on(rvb_device_alloc(ctx, n * sizeof(Impulse), &dev.upload), ctx, "rvb_device_alloc");
+    throw_on(rvb_copy_to_device(ctx, dev.upload, impulses.data(), n * sizeof(Impulse)), ctx, "rvb_copy_to_device");
+    dev.head = dev.upload;
+    dev.nhead = n;
+}
+
+// one channel: kernel on the staged input, result downloaded into a fresh vector whose device copy is remembered
+template <class Launch>
+std::vector<AttenuatedImpulse> attenuate_channel(rvb_ctx * ctx, size_t n, Launch launch)
+{
+    std::vector<AttenuatedImpulse> ret = uninitialized_vector<AttenuatedImpulse>(n);
+    if (n == 0) return ret;
+    void * d_out = nullptr;
+    throw_on(rvb_device_alloc(ctx, n * sizeof(AttenuatedImpulse), &d_out), ctx, "rvb_device_alloc");
+    int rc = launch(d_out);
+    if (rc == RVB_OK) rc = rvb_copy_to_host(ctx, ret.data(), d_out, n * sizeof(AttenuatedImpulse));
+    if (rc != RVB_OK) { (void) rvb_device_free(ctx, d_out); throw_on(rc, ctx, "attenuate"); }
+    Resident r;
+    r.host = ret.data(); r.count = n; r.elem = sizeof(AttenuatedImpulse);
+    r.device = d_out; r.device_count = n; r.owned = true;
+    resident_remember(r);                       // (frees d_out itself when residency is off)
+    return ret;
+}
+}  // namespace
+
 std::vector<std::vector<AttenuatedImpulse>> HrtfAttenuator::attenuate(const RaytracerResults & results, const cl_float3 & facing, const cl_float3 & up)
 {
-    std::vector<std::vector<AttenuatedImpulse>> attenuated(2);          // channels {0, 1}, rayverb.cpp:751
-    for (unsigned long ch = 0; ch < 2; ++ch)
-        attenuated[ch] = attenuate(results.mic, ch, facing, up, results.impulses);
+    // channels {0, 1}, rayverb.cpp:751.  The kernels run on the library's shared context: this object is usually a temporary
+    // (cmd/main.cpp:286) and the device copies of what it returns have to outlive it.
+    DeviceImpulses dev(shared_context());
+    stage_impulses(results.impulses, dev);
+    std::vector<std::vector<AttenuatedImpulse>> attenuated(2);
+    for (unsigned long ch = 0; ch < 2; ++ch) {
+        // [360][180] of cl_float8 is contiguous: exactly the flattened table of rayverb.cpp:774-780
+        const float * table = reinterpret_cast<const float *>(getHrtfData()[ch].data());
+        const cl_float3 mic = results.mic;
+        const size_t n = results.impulses.size();
+        attenuated[ch] = attenuate_channel(dev.ctx, n, [&](void * d_out) {
+            int rc = rvb_attenuate_hrtf_device(dev.ctx, mic.s, dev.head, dev.nhead, table, facing.s, up.s, ch, d_out);
+            if (rc == RVB_OK && dev.ntail)
+                rc = rvb_attenuate_hrtf_device(dev.ctx, mic.s, dev.tail, dev.ntail, table, facing.s, up.s, ch,
+                                               static_cast<char *>(d_out) + dev.nhead * sizeof(AttenuatedImpulse));
+            return rc;
+        });
+    }
     return attenuated;
 }
 
 std::vector<AttenuatedImpulse> HrtfAttenuator::attenuate(const cl_float3 & mic_pos, unsigned long channel, const cl_float3 & facing,
                                                          const cl_float3 & up, const std::vector<Impulse> & impulses)
 {
-    // [360][180] of cl_float8 is contiguous: exactly the flattened table of rayverb.cpp:774-780
     const float * table = reinterpret_cast<const float *>(getHrtfData()[channel].data());
     std::vector<AttenuatedImpulse> ret(impulses.size());
     check(rvb_attenuate_hrtf(context(), mic_pos.s, reinterpret_cast<const rvb_impulse *>(impulses.data()), impulses.size(), table,
@@ -286,9 +600,21 @@ SpeakerAttenuator::SpeakerAttenuator() {}
 
 std::vector<std::vector<AttenuatedImpulse>> SpeakerAttenuator::attenuate(const RaytracerResults & results, const std::vector<Speaker> & speakers)
 {
+    // the impulse array is staged ONCE for all speakers (the reference uploads it per speaker, rayverb.cpp:863-875)
+    DeviceImpulses dev(shared_context());
+    stage_impulses(results.impulses, dev);
     std::vector<std::vector<AttenuatedImpulse>> attenuated(speakers.size());
-    for (size_t i = 0; i < speakers.size(); ++i)
-        attenuated[i] = attenuate(results.mic, speakers[i], results.impulses);
+    const size_t n = results.impulses.size();
+    for (size_t i = 0; i < speakers.size(); ++i) {
+        const cl_float3 mic = results.mic;
+        const rvb_speaker * sp = reinterpret_cast<const rvb_speaker *>(&speakers[i]);
+        attenuated[i] = attenuate_channel(dev.ctx, n, [&](void * d_out) {
+            int rc = rvb_attenuate_speaker_device(dev.ctx, mic.s, dev.head, dev.nhead, sp, d_out);
+            if (rc == RVB_OK && dev.ntail)
+                rc = rvb_attenuate_speaker_device(dev.ctx, mic.s, dev.tail, dev.ntail, sp, static_cast<char *>(d_out) + dev.nhead * sizeof(AttenuatedImpulse));
+            return rc;
+        });
+    }
     return attenuated;
 }
 

@@ -14,7 +14,7 @@
         for (int i = 0; i < iters; ++i) {                                                             \
             asm volatile(ASM(0) ASM(1) ASM(2) ASM(3) ASM(4) ASM(5) ASM(6) ASM(7)                      \
                          ASM(0) ASM(1) ASM(2) ASM(3) ASM(4) ASM(5) ASM(6) ASM(7)                      \
-                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc"); \
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc", "s2", "s3"); \
         }                                                                                             \
         out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;           \
     }
@@ -28,6 +28,14 @@
 #define A_ANDOR(n) "v_and_or_b32 %" #n ", %" #n ", %8, %9\n"
 #define A_BCNT(n) "v_bcnt_u32_b32 %" #n ", %" #n ", %8\n"
 #define A_CNDMASK(n) "v_cndmask_b32 %" #n ", %" #n ", %8, vcc\n"
+#define A_CNDMASK64(n) "v_cndmask_b32_e64 %" #n ", %" #n ", %8, s[2:3]\n"
+#define A_ADD(n) "v_add_f32 %" #n ", %" #n ", %8\n"
+#define A_MUL(n) "v_mul_f32 %" #n ", %" #n ", %8\n"
+#define A_MOV(n) "v_mov_b32 %" #n ", %8\n"
+#define A_CMPSEL_VCC(n) "v_cmp_lt_f32 vcc, %" #n ", %8\ns_nop 1\nv_cndmask_b32 %" #n ", %" #n ", %9, vcc\n"
+#define A_CMPSEL_SGPR(n) "v_cmp_lt_f32_e64 s[2:3], %" #n ", %8\ns_nop 1\nv_cndmask_b32_e64 %" #n ", %" #n ", %9, s[2:3]\n"
+#define A_CMPSEL2_VCC(n) "v_cmp_lt_f32 vcc, %" #n ", %8\ns_nop 1\nv_cndmask_b32 %" #n ", %" #n ", %9, vcc\nv_cndmask_b32 %" #n ", %" #n ", %8, vcc\n"
+#define A_CMPSEL2_SGPR(n) "v_cmp_lt_f32_e64 s[2:3], %" #n ", %8\ns_nop 1\nv_cndmask_b32_e64 %" #n ", %" #n ", %9, s[2:3]\nv_cndmask_b32_e64 %" #n ", %" #n ", %8, s[2:3]\n"
 #define A_CMP(n) "v_cmp_lt_f32 vcc, %" #n ", %8\n"
 #define A_LSHLADD(n) "v_lshl_add_u32 %" #n ", %" #n ", 2, %8\n"
 #define A_MULLO(n) "v_mul_lo_u32 %" #n ", %" #n ", %8\n"
@@ -44,7 +52,7 @@
 BODY(fma, A_FMA) BODY(fma_mix, A_FMAMIX) BODY(perm, A_PERM) BODY(min_dpp, A_MINDPP) BODY(mov_dpp, A_MOVDPP) BODY(max3, A_MAX3)
 BODY(and_or, A_ANDOR) BODY(bcnt, A_BCNT) BODY(cndmask, A_CNDMASK) BODY(cmp, A_CMP) BODY(lshl_add, A_LSHLADD) BODY(mul_lo, A_MULLO)
 BODY(mul_u24, A_MUL24) BODY(bitop3, A_BITOP3) BODY(cvt_f16, A_CVT) BODY(rcp, A_RCP) BODY(sqrt, A_SQRT) BODY(min, A_MIN)
-BODY(div_fixup, A_DIVFIX) BODY(bpermute, A_BPERM)
+BODY(div_fixup, A_DIVFIX) BODY(bpermute, A_BPERM) BODY(cndmask_sgpr, A_CNDMASK64) BODY(cmpsel_vcc, A_CMPSEL_VCC) BODY(cmpsel_sgpr, A_CMPSEL_SGPR) BODY(cmpsel2_vcc, A_CMPSEL2_VCC) BODY(cmpsel2_sgpr, A_CMPSEL2_SGPR) BODY(add_f32, A_ADD) BODY(mul_f32, A_MUL) BODY(mov, A_MOV)
 
 
 // ---- binary64 forms (the correctly rounded exp of rvb_math.h air_attenuation is made of these) ----
@@ -122,7 +130,7 @@ int main()
         SHOW(fma_mix) SHOW(perm) SHOW(min_dpp) SHOW(mov_dpp) SHOW(max3) SHOW(and_or) SHOW(bcnt) SHOW(cndmask) SHOW(cmp) SHOW(lshl_add)
         SHOW(mul_lo) SHOW(mul_u24) SHOW(bitop3) SHOW(cvt_f16) SHOW(rcp) SHOW(sqrt) SHOW(min) SHOW(div_fixup) SHOW(bpermute)
         SHOW(fma_f64) SHOW(mul_f64) SHOW(add_f64) SHOW(rndne_f64) SHOW(ldexp_f64) SHOW(cvt_f32_f64) SHOW(cvt_f64_f32) SHOW(cvt_i32_f64)
-        SHOW(rcp_f64) SHOW(cmp_u64)
+        SHOW(rcp_f64) SHOW(cmp_u64) SHOW(cndmask_sgpr) SHOW(cmpsel_vcc) SHOW(cmpsel_sgpr) SHOW(cmpsel2_vcc) SHOW(cmpsel2_sgpr) SHOW(add_f32) SHOW(mul_f32) SHOW(mov)
     }
     return 0;
 }

@@ -52,6 +52,7 @@ struct Query {
     std::vector<float> stack_t;
     bool found = false;
     std::vector<uint32_t> held;  // postponed leaves
+    uint32_t skip = 0xFFFFFFFFu; // subtree that cannot hold a hit of this query (BuiltScene::skip_ref)
 };
 
 static float clamp_inv(float d)
@@ -82,6 +83,7 @@ struct Sim {
         q.stack.clear(); q.stack_t.clear();
         q.found = false;
         q.held.clear();
+        q.skip = 0xFFFFFFFFu;
     }
     float limit(const Query & q) const { return fmaf(q.best_t, 1.0f + cull_rel, cull_abs); }
     void pop(Query & q)
@@ -114,7 +116,7 @@ struct Sim {
             float tz0 = fmaf(loz, q.iz, -q.oiz), tz1 = fmaf(hiz, q.iz, -q.oiz);
             float a = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), neg_cull));
             float b = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), lim));
-            ok[c] = a <= b && ch.ref != RVB_BVH_EMPTY;
+            ok[c] = a <= b && ch.ref != RVB_BVH_EMPTY && ch.ref != q.skip;
             tn[c] = fmaxf(a, 0.0f);
             nok += ok[c];
         }
@@ -203,6 +205,25 @@ int main(int argc, char ** argv)
         printf("nodes %zu tris %zu depth %u stack_need %u | leaves %zu with 1/2/3/4 tris: %zu %zu %zu %zu | nodes with 1/2/3/4 children: %zu %zu %zu %zu\n",
                base.bs.nodes.size(), base.bs.tris.size(), base.bs.depth, base.bs.stack_need, leaves, hist[1], hist[2], hist[3], hist[4], kids[1], kids[2], kids[3], kids[4]);
     }
+    {
+        // own-plane skip statistics: triangles by the tree level of the node that holds their skip child
+        std::vector<int> slot_level(base.bs.nodes.size() * 4 + 4, -1);
+        size_t by_lvl[16] = {0}, none = 0, ngroups = 0;
+        std::vector<uint32_t> parent_level_of_ref;
+        for (const BvhTri & t : base.bs.tris) {
+            const TriSkip & sk = base.bs.skip[t.index];
+            if (sk.group != 0xFFFFFFFFu && sk.group + 1 > ngroups) ngroups = sk.group + 1;
+            if (sk.ref == RVB_BVH_EMPTY) { ++none; continue; }
+            // find the level: search the node that has this child ref (refs are unique)
+            int lvl = 15;
+            if (!(sk.ref & RVB_BVH_LEAF)) lvl = base.level[sk.ref >> RVB_BVH_NODE_SHIFT] - 1;
+            else lvl = 14;                                // leaf-level skip
+            ++by_lvl[lvl < 0 ? 0 : lvl];
+        }
+        printf("own-plane skip: %zu plane groups; triangles without a skip subtree %zu; by level of the skipped child's parent:", ngroups, none);
+        for (int l = 0; l < 14; ++l) if (by_lvl[l]) printf(" L%d %zu", l, by_lvl[l]);
+        printf(" leaf-only %zu\n", by_lvl[14]);
+    }
     const float * dirs = (const float *) db.data();
     const bool verify = getenv("TRAVSIM_VERIFY") != nullptr;
     const double grazing = getenv("TRAVSIM_GRAZING") ? atof(getenv("TRAVSIM_GRAZING")) : 0.0;
@@ -229,7 +250,8 @@ int main(int argc, char ** argv)
         const int sched = p;
         const int T = p >= 2 ? (p - 1) * 2 : 1;
         unsigned long long w_node = 0, w_leaf = 0, w_done = 0, bounces = 0, q_node_active = 0, q_leaf_active = 0, q_done_active = 0, maxstack = 0;
-        std::vector<v3> hitpts; std::vector<uint32_t> hittri;
+        std::vector<v3> hitpts; std::vector<uint32_t> hittri; std::vector<float> hitthr;
+        unsigned long long skips_set = 0, skips_possible = 0;
         for (uint64_t w = 0; w < nrays; w += 16) {
             Query q[16]; Ray r[16];
             enum { NODE, LEAF, DONE, IDLE } st[16];
@@ -319,11 +341,16 @@ int main(int argc, char ** argv)
                         const TriShade & sh = s.bs.shade[q[i].best_i];
                         v3 n = mk3(sh.n[0], sh.n[1], sh.n[2]);
                         v3 pnt = r[i].o + r[i].d * q[i].best_t;
-                        if (hitpts.size() < 400000) { hitpts.push_back(pnt); hittri.push_back(q[i].best_i); }
+                        const TriSkip & sk = s.bs.skip[q[i].best_i];
+                        const float thr = fmaf(sk.b, q[i].best_t, sk.a), cosine = fabsf(dot3(n, r[i].d));
+                        const bool use_skip = getenv("TRAVSIM_SKIP") != nullptr;
+                        if (hitpts.size() < 400000) { hitpts.push_back(pnt); hittri.push_back(q[i].best_i); hitthr.push_back(thr); }
                         r[i].d = reflect3(n, r[i].d);
                         r[i].o = pnt;
                         if (++r[i].bounce >= nrefl) { st[i] = IDLE; continue; }
                         s.begin(q[i], r[i].o, r[i].d, false, 0.0f);
+                        ++skips_possible;
+                        if (use_skip && sk.ref != RVB_BVH_EMPTY && cosine > thr) { q[i].skip = sk.ref; ++skips_set; }
                         st[i] = NODE;
                     }
                 }
@@ -334,6 +361,7 @@ int main(int argc, char ** argv)
                sched, T, (double) s.node_steps / bounces, (double) s.leaf_steps / bounces, wn, wl, wd,
                (double) q_node_active / w_node, (double) q_leaf_active / w_leaf, (double) q_done_active / w_done,
                wn * C_NODE + wl * C_LEAF + wd * C_DONE);
+        if (p == 0) printf("   own-plane skip set on %.1f %% of the queries\n", 100.0 * skips_set / (skips_possible ? skips_possible : 1));
         if (p == 0) {
             printf("   node visits per bounce by tree level (children hit per visit):");
             for (int l = 0; l < 12; ++l) if (s.by_level[l]) printf(" L%d %.2f (%.2f)", l, (double) s.by_level[l] / bounces, (double) s.hits_by_level[l] / s.by_level[l]);
@@ -361,6 +389,13 @@ int main(int argc, char ** argv)
                         ++nextj[i];
                         v3 b2p = mic - pnt;
                         sh.begin(q[i], pnt, normalize3(b2p), true, length3(b2p));
+                        {
+                            const uint32_t rec = order[w0 + (nextj[i] - 1) * 16 + i];
+                            const TriSkip & sk = base.bs.skip[hittri[rec]];
+                            const TriShade & shd = base.bs.shade[hittri[rec]];
+                            const float cosine = fabsf(dot3(mk3(shd.n[0], shd.n[1], shd.n[2]), q[i].d));
+                            if (getenv("TRAVSIM_SKIP") && sk.ref != RVB_BVH_EMPTY && cosine > hitthr[rec]) q[i].skip = sk.ref;
+                        }
                         st[i] = NODE;
                     };
                     for (int i = 0; i < 16; ++i) { nextj[i] = 0; start(i); }
