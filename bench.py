@@ -6,9 +6,14 @@ One step = one full impulse-response generation for one batch of rays, everythin
     ->  fused attenuate + predelay + time-binning into [channels][8][nbins]  (-> RCCL sum over ranks)
 Workload at N=1 = BASELINE.json configs[1]: cathedral stand-in (~75k triangles; Sibenik itself is
 not available offline), 100k rays x 128 bounces x 8 bands, two cardioid speakers, 44.1 kHz,
-trim_predelay.  With N>1 ranks (one process per GPU, torch.distributed/RCCL) every rank traces its own
-100k-ray shard of one seeded global ray set (weak scaling, BASELINE.json configs[2] at N=8 = 800k rays)
-and the per-band histograms are summed with one all-reduce; there is no other data-path collective.
+trim_predelay.  With N>1 ranks (one process per GPU, torch.distributed/RCCL) the workload is configs[2]'s
+shape: every rank traces its contiguous 125k-ray shard of one seeded global set of N x 125k rays (N=8: the
+config's 1M rays; weak scaling) and the per-band histograms are summed with one all-reduce; there is no other
+data-path collective.
+
+The binning runs in EXACT mode by default: every rank's histogram is the reference's serial float sum over its
+impulses, bit for bit (tests/test_gpu_fullsize.py checks it against the oracle chain at this very size).  The
+float-atomic mode is reported beside it (`fast_mode`) with its measured distance from the exact histogram.
 
 Prints ONE JSON line on rank 0.
 """
@@ -28,8 +33,10 @@ rvb_import.load()
 from parallel_reverb_raytracer_amd import capi, distributed, dtypes, scenes  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-VALU_PEAK_GINST = 256 * 4 * 2.4 / 4   # 256 CUs x 4 SIMDs, one VALU wave-instruction per 4 cycles at 2.4 GHz = 614.4 G/s
-PMC_FILE = "r01e_pmc_n1.json"
+# the guide's vector issue rate: v_fma_f32 (wave64) 2 cycles on each of 256 x 4 SIMDs at 2.4 GHz
+VALU_FMA_PEAK_GINST = 256 * 4 * 2.4 / 2
+PMC_FILE = "r02_pmc_n1.json"      # committed PMC passes of this command (tools/profile.sh): instruction mix, lane utilisation, HBM bytes
+BYTES_PER_BOUNCE = 69.75          # 64 B Impulse per bounce + (16 B direction + 10 x 72 B image slots) per ray at 128 bounces
 
 
 def parse():
@@ -37,12 +44,14 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=4)
-    p.add_argument("--rays", type=int, default=100000, help="rays per GPU")
+    p.add_argument("--rays", type=int, default=0, help="rays per GPU (default: 100000 on one GPU = config C2, 125000 per GPU otherwise = config C3's share)")
     p.add_argument("--reflections", type=int, default=128)
     p.add_argument("--triangles", type=int, default=75000)
     p.add_argument("--sample-rate", type=float, default=44100.0)
-    p.add_argument("--mode", choices=["fast", "exact"], default="fast")
+    p.add_argument("--mode", choices=["fast", "exact"], default="exact")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-extras", action="store_true", help="only the timed region and the per-kernel pass (profiling runs): no fast-mode leg, "
+                   "no fast-vs-exact comparison, no API-flow leg, no attenuate probe")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     p.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
@@ -87,6 +96,22 @@ def cpu_baseline(scene, mic, src, nrefl, target_seconds):
                       % (what, done, nrefl, spent)}
 
 
+def fast_vs_exact(fast, exact):
+    """Distance of the float-atomic histogram from the serial-order one (torch tensors [channels][8][nbins] on the GPU): the claimed
+    tolerance is 1e-5 x the band's largest |value| (sign-alternating volumes cancel inside a bin: a relative bar per band-bin is
+    not meaningful where the sum is ~0); the fraction of band-bins outside a pure 1e-5 relative error is reported with it."""
+    import torch
+    f, e = fast.double(), exact.double()
+    err = (f - e).abs()
+    band_max = e.abs().amax(dim=2, keepdim=True).clamp_min(1e-300)
+    nonzero = e != 0
+    rel = torch.where(nonzero, err / e.abs().clamp_min(1e-300), torch.zeros_like(err))
+    outside = (rel > 1e-5) | (~nonzero & (err > 0))
+    return {"max_abs_err_over_band_max": float((err / band_max).max()), "claimed_tolerance": 1e-5,
+            "fraction_band_bins_outside_1e-5_relative": float(outside.double().mean()),
+            "band_bins": int(err.numel()), "band_bins_differing": int((err > 0).sum())}
+
+
 def main():
     args = parse()
     # Rank 0 owes the driver ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner to
@@ -120,12 +145,14 @@ def main():
 
     (scene, info) = scenes.cathedral(args.triangles)
     mic, src = info["mic"], info["source"]
-    nrays, nrefl, sr = args.rays, args.reflections, args.sample_rate
+    rays_per_gpu = args.rays if args.rays else (100000 if world == 1 else 125000)
+    nrefl, sr = args.reflections, args.sample_rate
     speakers_dir, speakers_coeff = [(-1, 0, -1), (1, 0, -1)], [0.5, 0.5]
     mode = capi.IR_FAST if args.mode == "fast" else capi.IR_EXACT
 
     # this rank's contiguous shard of the global seeded ray set, resident in HBM before timing starts
-    dirs = torch.from_numpy(np.ascontiguousarray(scenes.sphere_directions(nrays, seed=1, first=rank * nrays))).to(device)
+    first_ray, nrays = distributed.shard_range(rays_per_gpu * world, rank, world)
+    dirs = torch.from_numpy(np.ascontiguousarray(scenes.sphere_directions(nrays, seed=1, first=first_ray))).to(device)
     torch.cuda.synchronize()
     contexts, scene_ms = [], 0.0
     for _ in range(max(1, args.contexts)):
@@ -142,13 +169,14 @@ def main():
     state = {}
     trace_args = (mic, src, nrefl, dtypes.AIR_COEFFICIENTS)
 
-    def ir_kwargs(sink):
+    def ir_kwargs(sink, ir_mode=None):
         def on_stage(_name, tracer):
             if sink is not None:
                 for k, v in tracer.last_timings():
                     sink.setdefault(k, []).append(v)
-        return dict(speakers_dir=speakers_dir, speakers_coeff=speakers_coeff, sample_rate=sr, trim_predelay=True, mode=mode,
-                    rank=rank, world=world, ray_offset=rank * nrays, device=device, on_stage=on_stage, collectives=grouped)
+        return dict(speakers_dir=speakers_dir, speakers_coeff=speakers_coeff, sample_rate=sr, trim_predelay=True,
+                    mode=mode if ir_mode is None else ir_mode,
+                    rank=rank, world=world, ray_offset=first_ray, device=device, on_stage=on_stage, collectives=grouped)
 
     def keep(hist, info, _tracer):
         state.update(hist=hist, nbins=info["nbins"], images=info["images"], predelay=info["predelay"])
@@ -161,8 +189,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # untimed: every context allocates its buffers, then one IR strictly alone for the per-kernel "solo" durations and the
-    # single-IR latency (the timed region below overlaps two IRs when --contexts 2)
+    def timed(steps, kwargs):
+        fence()
+        t0 = time.perf_counter()
+        pipeline.run(steps, trace_args, kwargs, keep)
+        fence()
+        elapsed = time.perf_counter() - t0
+        if grouped:
+            t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t[0])
+        return elapsed
+
+    # untimed: every context allocates its buffers, then a few IRs strictly alone for the per-kernel "solo" durations and the
+    # latency of one IR — to the histogram in HBM (ir_gen_wall_ms) and on to pinned host memory (ir_gen_to_host_ms)
     for c in contexts:
         distributed.generate_ir(c, *trace_args, **ir_kwargs(None))
     fence()
@@ -172,24 +212,41 @@ def main():
         distributed.generate_ir(ctx, *trace_args, **ir_kwargs(solo_ms))
         ctx.synchronize()
     solo_latency_ms = (time.perf_counter() - t0) * 1e3 / solo_irs
-    pipeline.run(args.warmup, trace_args, ir_kwargs(None), keep)
+    hist, _ = distributed.generate_ir(ctx, *trace_args, **ir_kwargs(None))
+    host_hist = torch.empty(hist.shape, dtype=hist.dtype, pin_memory=True)
     fence()
     t0 = time.perf_counter()
-    pipeline.run(args.steps, trace_args, ir_kwargs(kernel_ms), keep)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if grouped:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+    for _ in range(solo_irs):
+        hist, _ = distributed.generate_ir(ctx, *trace_args, **ir_kwargs(None))
+        host_hist.copy_(hist, non_blocking=True)
+        torch.cuda.synchronize()
+    to_host_latency_ms = (time.perf_counter() - t0) * 1e3 / solo_irs
+
+    pipeline.run(args.warmup, trace_args, ir_kwargs(None), keep)
+    elapsed = timed(args.steps, ir_kwargs(kernel_ms))
 
     ms_per_step = elapsed / args.steps * 1e3
-    bounces_per_step = world * nrays * nrefl
+    bounces_per_step = world * rays_per_gpu * nrefl
     value = bounces_per_step / (elapsed / args.steps)
     executed = ctx.executed_bounces()
 
-    attenuate_probe = None
-    if rank == 0:
+    # the other binning mode through the same timed pipeline, and how far the float-atomic histogram is from the exact one
+    other_mode, comparison = None, None
+    if not args.no_extras:
+        other = capi.IR_EXACT if mode == capi.IR_FAST else capi.IR_FAST
+        pipeline.run(2, trace_args, ir_kwargs(None, other), keep)
+        other_elapsed = timed(args.steps, ir_kwargs(None, other))
+        other_mode = {"mode": "exact" if other == capi.IR_EXACT else "fast", "value": bounces_per_step / (other_elapsed / args.steps),
+                      "ms_per_step": other_elapsed / args.steps * 1e3}
+        h_fast, _ = distributed.generate_ir(ctx, *trace_args, **ir_kwargs(None, capi.IR_FAST))
+        h_exact, _ = distributed.generate_ir(ctx, *trace_args, **ir_kwargs(None, capi.IR_EXACT))
+        torch.cuda.synchronize()
+        if rank == 0:
+            comparison = fast_vs_exact(h_fast, h_exact)
+        del h_fast, h_exact
+
+    attenuate_probe, api_flow = None, None
+    if rank == 0 and not args.no_extras:
         # the materialised attenuate kernel (reference kernel `attenuate`, what SpeakerAttenuator::attenuate launches per
         # channel): 64 B read + 64 B written per impulse, on the traced impulses of this very workload, HBM to HBM.
         d_in, n_imp = ctx.diffuse_device()
@@ -202,62 +259,79 @@ def main():
             times.append(dict(ctx.last_timings()).get("attenuate_kernel"))
         attenuate_probe = {"impulses": int(n_imp), "ms": float(np.mean(times[1:])), "bytes": 128.0 * n_imp}
         del out_buf
+        if world == 1:
+            # the same workload through the reference's own API (cmd/main.cpp:241-298): Raytracer::raytrace -> getAllRaw ->
+            # SpeakerAttenuator::attenuate -> fixPredelay -> flattenImpulses, every stage's result handed over as std::vector
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import api_flow_run
+                api_flow = api_flow_run.run(nrays, nrefl, args.triangles, repeats=3, env={"RVB_DEVICE": str(local_rank)})
+                api_flow["what"] = ("tools/api_flow.cpp: the reference's call sequence through the C++ mirror of its classes, best of 3; "
+                                    "the PCIe floor of that API is 3 x 0.82 GB of result vectors")
+            except Exception as e:      # the leg is a report, not the metric
+                api_flow = {"error": str(e)[:300]}
     if rank == 0:
         avg = {k: float(np.mean(v)) for k, v in kernel_ms.items()}
-        # algorithmic bytes (materialised formulation; split per kernel in DESIGN.md)
-        algorithmic = {
-            "record_sort_kernels": 0.0,
-            "path_kernel": 16.0 * nrays,
-            "image_kernel": 720.0 * nrays,
-            "shadow_kernel": 64.0 * nrays * nrefl,
-            "time_range_kernel": 64.0 * nrays * nrefl,
-            "histogram_fast_kernel": 64.0 * nrays * nrefl,
-        }
         solo = {k: float(np.mean(v)) for k, v in solo_ms.items()}       # one IR alone on the GPU (untimed pass above)
         trace_ms = sum(solo.get(k, 0.0) for k in ("path_kernel", "image_kernel", "shadow_kernel"))
         dominant = max(solo, key=solo.get)                              # by the time the kernel itself needs
         # Kernel durations for the rooflines come from the solo pass (HIP events around each launch with one IR on the GPU): in the
-        # timed region the kernels of two IRs interleave and the events around a launch then span its neighbour's work as well.
+        # timed region the kernels of several IRs interleave and the events around a launch then span its neighbour's work as well.
         # rocprofv3 --kernel-trace --stats of `bench.py --contexts 1` agrees with them (profiles/).
-        ach = algorithmic.get(dominant, 0.0) / (solo[dominant] * 1e-3) / 1e9
-        # HBM traffic per launch from the committed PMC passes of this same command (profiles/), if the workload matches
-        traffic, valu_insts, valu_per_ir = {}, {}, None
+        pmc = {}
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
+            loaded = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
             if (nrays, nrefl, args.triangles, world) == (100000, 128, 75000, 1):
-                # per IR: the binning kernel runs twice per IR (diffuse impulses, then the few image sources) under one timing label
-                traffic = {k: v.get("hbm_bytes_per_ir", v["hbm_bytes_per_launch"]) for k, v in pmc["kernels"].items() if "hbm_bytes_per_launch" in v}
-                valu_insts = {k: v["SQ_INSTS_VALU"] for k, v in pmc["kernels"].items() if "SQ_INSTS_VALU" in v}
-                valu_per_ir = pmc.get("valu_wave_instructions_per_ir")
+                pmc = loaded["kernels"]
         except (OSError, ValueError, KeyError):
             pass
+        from_profile = "profiles/%s (rocprofv3 --pmc passes of this command, per launch)" % PMC_FILE
+
+        def hbm_traffic(k):
+            v = pmc.get(k, {})
+            return v.get("hbm_bytes_per_ir", v.get("hbm_bytes_per_launch"))
+
+        # the contract's roofline line, for the dominant kernel: the trace stage's algorithmic bytes (69.75 B per
+        # ray-bounce, ALL of them charged to this one kernel) over its launch duration, against HBM.  A ray's bounces are a dependent
+        # chain over a cache-resident scene, so this fraction is small by construction; what bounds the kernel is VALU issue
+        # (roofline_valu), and the HBM-bound kernels of the path are in roofline_stream.
+        ach = BYTES_PER_BOUNCE * nrays * nrefl / (solo[dominant] * 1e-3) / 1e9
         roofline = {"kernel": dominant, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic.get(dominant),
-                    "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)" % PMC_FILE if traffic else None,
-                    "avg_launch_ms": solo[dominant], "elapsed_ms_in_timed_region": avg.get(dominant),
-                    "note": "avg_launch_ms: HIP events around the launch with one IR on the GPU (in the timed region two IRs share it); "
-                            "trace kernels are VALU-issue-bound by construction (scene + BVH are cache-resident): see roofline_valu; "
-                            "the HBM-bound kernels of the path are reported in roofline_stream"}
-        # What actually bounds the trace kernels: VALU issue.  achieved = VALU wave-instructions (PMC SQ_INSTS_VALU of this same
-        # command, a property of the workload) / time; peak = 1024 SIMDs x one wave-instruction per 4 cycles.  Per kernel against
-        # its duration when it has the GPU to itself (kernel_ms_solo: in the timed region two IRs share the GPU and a kernel's
-        # elapsed time includes its neighbour's work); whole_step = every kernel of one IR against the timed region's ms_per_step.
+                    "frac": ach / HBM_PEAK_GBS, "traffic": hbm_traffic(dominant),
+                    "traffic_source": from_profile + ", (2 x FETCH_SIZE + WRITE_SIZE) x 1024" if hbm_traffic(dominant) else None,
+                    "algorithmic_bytes_per_launch": BYTES_PER_BOUNCE * nrays * nrefl, "avg_launch_ms": solo[dominant],
+                    "elapsed_ms_in_timed_region": avg.get(dominant),
+                    "note": "avg_launch_ms: HIP events around the launch on the context's stream with one IR on the GPU; the whole trace "
+                            "stage's bytes are charged to this kernel; it is VALU-issue-bound (roofline_valu)"}
+        # VALU issue model: the kernel's dynamic instruction mix (per-class PMC counters) x the issue cost of each class measured on
+        # this chip at 8 waves per SIMD (tools/inst_probe.hip -> profiles/r02_inst_probe.log) = the time the launch needs if every
+        # SIMD issued VALU work back to back; frac = that time / the measured launch time.  frac_of_fma_peak prices every
+        # instruction at the guide's v_fma_f32 rate instead (2 cycles per wave64 instruction).  useful_lane_fraction = active lanes
+        # per issued VALU instruction / 64 (SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU x 64)): masked-off lanes of the quad
+        # kernels (a wave's 16 rays are not all in the step kind being executed) are issued but do nothing.
         valu = {}
-        for k in ("path_kernel", "shadow_kernel"):
-            if k in valu_insts and solo.get(k):
-                a = valu_insts[k] / (solo[k] * 1e-3) / 1e9
-                valu[k] = {"bound": "valu_issue", "achieved": a, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
-                           "frac": a / VALU_PEAK_GINST, "avg_launch_ms": solo[k], "valu_instructions_per_launch": valu_insts[k]}
-        if valu_per_ir:
-            a = valu_per_ir * world / (elapsed / args.steps) / 1e9
-            valu["whole_step"] = {"bound": "valu_issue", "achieved": a, "peak": VALU_PEAK_GINST * world, "unit": "G wave-instructions/s",
-                                  "frac": a / (VALU_PEAK_GINST * world), "valu_instructions_per_ir": valu_per_ir}
+        for k in ("path_kernel", "shadow_kernel", "image_kernel"):
+            v = pmc.get(k, {})
+            if "SQ_INSTS_VALU" in v and solo.get(k):
+                a = v["SQ_INSTS_VALU"] / (solo[k] * 1e-3) / 1e9
+                entry = {"bound": "valu_issue", "achieved": a, "unit": "G wave-instructions/s", "avg_launch_ms": solo[k],
+                         "valu_instructions_per_launch": v["SQ_INSTS_VALU"], "numerators": from_profile,
+                         "frac_of_fma_peak": a / VALU_FMA_PEAK_GINST, "fma_peak": VALU_FMA_PEAK_GINST}
+                if v.get("valu_issue_model_ms"):
+                    entry.update(peak=v["SQ_INSTS_VALU"] / (v["valu_issue_model_ms"] * 1e-3) / 1e9, frac=v["valu_issue_model_ms"] / solo[k],
+                                 issue_model_ms=v["valu_issue_model_ms"], instruction_mix=v.get("valu_mix"))
+                if v.get("valu_lane_utilisation") is not None:
+                    entry["useful_lane_fraction"] = v["valu_lane_utilisation"]
+                valu[k] = entry
         stream = {}
-        for k in ("shadow_kernel", "time_range_kernel", "histogram_fast_kernel"):
+        algorithmic = {"shadow_kernel": 128.0 * nrays * nrefl,          # 64-byte work record read, 64-byte Impulse written
+                       "time_range_kernel": 64.0 * nrays * nrefl, "histogram_fast_kernel": 64.0 * nrays * nrefl,
+                       "exact_mode": (64.0 + 8.0 + 64.0) * nrays * nrefl}   # keys pass, (key, index) pairs out, gather of the records
+        for k in ("shadow_kernel", "time_range_kernel", "histogram_fast_kernel", "exact_mode"):
             if k in solo and solo[k] > 0:                # against the kernel's duration with the GPU to itself
                 a = algorithmic[k] / (solo[k] * 1e-3) / 1e9
                 stream[k] = {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
-                             "avg_launch_ms": solo[k], "traffic": traffic.get(k)}
+                             "avg_launch_ms": solo[k], "traffic": hbm_traffic(k)}
         if attenuate_probe and attenuate_probe["ms"]:
             a = attenuate_probe["bytes"] / (attenuate_probe["ms"] * 1e-3) / 1e9
             stream["attenuate_kernel"] = {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
@@ -268,13 +342,18 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "cathedral stand-in (Sibenik unavailable offline), %d triangles, %d rays/GPU x %d bounces x 8 bands, "
-                                   "2 cardioid speakers, %.0f Hz, trim_predelay, output_mode all, histogram mode %s"
-                                   % (scene[0].shape[0], nrays, nrefl, sr, args.mode),
-                       "triangles": int(scene[0].shape[0]), "rays_per_gpu": nrays, "reflections": nrefl,
+                                   "2 cardioid speakers, %.0f Hz, trim_predelay, output_mode all, histogram mode %s%s"
+                                   % (scene[0].shape[0], rays_per_gpu, nrefl, sr, args.mode,
+                                      "" if world == 1 else " (BASELINE configs[2]'s shape: %d rays over %d GPUs)" % (rays_per_gpu * world, world)),
+                       "triangles": int(scene[0].shape[0]), "rays_per_gpu": rays_per_gpu, "reflections": nrefl,
+                       "histogram_mode": args.mode + (": every rank's histogram is the reference's serial float sum over its impulses, bit for bit"
+                                                      if args.mode == "exact" else ": float atomics, order-dependent in the last bits"),
+                       "histogram_seconds": state["nbins"] / sr,
                        "sharding": "ray-range shards, replicated scene, one all-reduce(sum) of [2][8][nbins] histograms",
                        "pipelining": "%d contexts per GPU take turns: traces are enqueued %d at a time, the next group before the current one is finished"
                                      % (len(contexts), max(1, len(contexts) // 2))},
-            "ir_gen_wall_ms": solo_latency_ms, "contexts_per_gpu": len(contexts),
+            "ir_gen_wall_ms": solo_latency_ms, "ir_gen_to_host_ms": to_host_latency_ms, "contexts_per_gpu": len(contexts),
+            "fast_mode" if args.mode == "exact" else "exact_mode": other_mode, "fast_vs_exact": comparison, "api_flow": api_flow,
             "trace_only_ray_bounces_per_sec": (nrays * nrefl) / (trace_ms * 1e-3) if trace_ms else None,
             "executed_bounces_rank0": int(executed), "nominal_bounces_rank0": nrays * nrefl,
             "kernel_elapsed_ms_timed_region": avg, "kernel_ms": solo, "nbins": state["nbins"], "image_sources": state["images"], "predelay_s": state["predelay"],

@@ -24,6 +24,7 @@
 #include <vector>
 
 struct rvb_ctx;
+struct rvb_multi;
 
 // ---- time binning / predelay (reference rayverb.h:24-97) ----------------------------------------
 
@@ -130,6 +131,10 @@ private:
     void upload(std::vector<Triangle> & triangles, std::vector<cl_float3> & vertices, std::vector<Surface> & surfaces);
     void fetchDiffuse(std::vector<Impulse> & out);
     std::vector<Impulse> mergedImages(bool removeDirect);
+
+    // RVB_DEVICES=N (N > 1): the trace is sharded over GPUs 0 .. N-1 of the node (rvb_multi_*, ray-range shards; results are the
+    // bytes one device gives).  The reference itself drives one device (rayverb.cpp:163).
+    std::shared_ptr<rvb_multi> multi_;
 
     const unsigned long nreflections;
     unsigned long nrays;

@@ -194,6 +194,40 @@ int rvb_fix_predelay_device(rvb_ctx * ctx, void * d_attenuated, uint64_t n, floa
 int rvb_flatten_device(rvb_ctx * ctx, const void * d_attenuated, uint64_t n, float sample_rate,
                        float * out, uint64_t capacity_bins, uint64_t * nbins);
 
+/* ---- several GPUs of one node (csrc/multi.hip) ---------------------------------------------------------------------------
+ * The reference drives ONE device (rayverb.cpp:163, :176-177).  An rvb_multi owns one rvb_ctx and one host thread per listed
+ * device: the scene is replicated, device g traces the contiguous ray range [g N / D, (g+1) N / D) of the directions handed to
+ * rvb_multi_set_directions, image-source candidates are merged with the reference's lowest-ray-wins rule (rayverb.cpp:654-676)
+ * and the per-band histograms are combined on the devices:
+ *   RVB_IR_EXACT  the devices continue ONE left-to-right float sum in ray order (a chain of peer copies): bit-identical to a
+ *                 single context and to the reference's flattenImpulses;
+ *   RVB_IR_FAST   every device bins its shard at once, then one RCCL ncclAllReduce(sum) over xGMI (librccl.so is loaded at run
+ *                 time; a device list RCCL cannot serve — the same GPU twice — is summed with peer copies instead).
+ * devices == NULL means 0 .. ndevices-1.  Not thread-safe, like rvb_ctx. */
+typedef struct rvb_multi rvb_multi;
+enum { RVB_MULTI_REHEARSE_RCCL = 1 };     /* flags: run the RCCL all-reduce even for a single device (exercises the library binding) */
+int rvb_multi_create(rvb_multi ** out, const int * devices, int ndevices, unsigned flags);
+void rvb_multi_destroy(rvb_multi * m);
+const char * rvb_multi_last_error(const rvb_multi * m);
+int rvb_multi_devices(const rvb_multi * m);
+/* The context of device slot `index` and the ray range it traced (e.g. to run independent (source, listener) pairs per device). */
+int rvb_multi_context(rvb_multi * m, int index, rvb_ctx ** ctx, uint64_t * first_ray, uint64_t * nrays);
+int rvb_multi_used_rccl(const rvb_multi * m);            /* 1 if the last RVB_IR_FAST histogram was summed by RCCL */
+int rvb_multi_set_scene(rvb_multi * m, const rvb_triangle * triangles, uint64_t ntriangles, const rvb_float3 * vertices, uint64_t nvertices,
+                        const rvb_surface * surfaces, uint64_t nsurfaces);
+int rvb_multi_set_directions(rvb_multi * m, const rvb_float3 * directions, uint64_t nrays);
+/* Raytracer::raytrace on all devices at once (blocking, like the reference's). */
+int rvb_multi_trace(rvb_multi * m, const float mic[3], const float source[3], uint64_t nreflections, const float air_coefficient[8]);
+/* getRawDiffuse / getRawImages over all shards: ray-major [nrays * nreflections]; merged image sources in std::map key order. */
+int rvb_multi_get_diffuse(rvb_multi * m, rvb_impulse * out);
+int rvb_multi_get_images(rvb_multi * m, int remove_direct, rvb_impulse * out, uint64_t capacity, uint64_t * count);
+/* attenuate -> fixPredelay -> flattenImpulses over all shards; out (host) is [nchannels][8][*nbins]; out == NULL reports *nbins. */
+int rvb_multi_ir_speakers(rvb_multi * m, const float mic[3], const rvb_speaker * speakers, uint64_t nspeakers, int which, int remove_direct,
+                          int trim_predelay, float sample_rate, int mode, float * out, uint64_t capacity_bins, uint64_t * nbins);
+int rvb_multi_ir_hrtf(rvb_multi * m, const float mic[3], const float * table /* [2][360*180*8] */, const float facing[3], const float up[3],
+                      int which, int remove_direct, int trim_predelay, float sample_rate, int mode,
+                      float * out, uint64_t capacity_bins, uint64_t * nbins);
+
 /* ---- measurement hooks (bench.py) ------------------------------------------------------------
  * Durations in milliseconds of the kernels of the last rvb_trace / rvb_ir_accumulate, taken with
  * HIP events on the context's stream; names is a ';'-separated list matching ms[]. */

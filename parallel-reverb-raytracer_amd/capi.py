@@ -31,6 +31,9 @@ SYMBOLS = [
     "rvb_ir_configure_speakers", "rvb_ir_configure_hrtf", "rvb_ir_time_range", "rvb_ir_bins", "rvb_ir_accumulate",
     "rvb_ir_download", "rvb_last_timings", "rvb_debug_stamps", "rvb_executed_bounces",
     "rvb_device_alloc", "rvb_device_free", "rvb_copy_to_host", "rvb_copy_to_device", "rvb_fix_predelay_device", "rvb_flatten_device",
+    "rvb_multi_create", "rvb_multi_destroy", "rvb_multi_last_error", "rvb_multi_devices", "rvb_multi_context", "rvb_multi_used_rccl",
+    "rvb_multi_set_scene", "rvb_multi_set_directions", "rvb_multi_trace", "rvb_multi_get_diffuse", "rvb_multi_get_images",
+    "rvb_multi_ir_speakers", "rvb_multi_ir_hrtf",
 ]
 
 _vp = ctypes.c_void_p
@@ -66,6 +69,10 @@ def load_library():
         lib.rvb_ir_bins.argtypes = [ctypes.c_float, ctypes.c_float, ctypes.c_float]
         lib.rvb_destroy.restype = None
         lib.rvb_destroy.argtypes = [_vp]
+        lib.rvb_multi_destroy.restype = None
+        lib.rvb_multi_destroy.argtypes = [_vp]
+        lib.rvb_multi_last_error.restype = ctypes.c_char_p
+        lib.rvb_multi_last_error.argtypes = [_vp]
         _lib = lib
     return _lib
 
@@ -332,4 +339,88 @@ class Context:
         out = np.zeros((self.nchannels, 8, nbins.value), dtype=np.float32)
         self._check(self.lib.rvb_ir_download(self.handle, ctypes.c_int(int(trim_predelay)), ctypes.c_float(sample_rate),
                                              ctypes.c_int(mode), _ptr(out), _u64(nbins.value), ctypes.byref(nbins)))
+        return out
+
+
+MULTI_REHEARSE_RCCL = 1
+
+
+class MultiContext:
+    """Several GPUs of one node behind the C-ABI (rvb_multi_*): ray shards, merged image sources, histograms combined on the
+    devices (exact mode: one chained serial sum, bit-identical to a single context; fast mode: RCCL all-reduce)."""
+
+    def __init__(self, devices, flags=0):
+        self.lib = load_library()
+        self.handle = _vp()
+        devs = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+        rc = self.lib.rvb_multi_create(ctypes.byref(self.handle), devs, ctypes.c_int(len(devices)), ctypes.c_uint(flags))
+        if rc:
+            raise RvbError(rc, self.lib.rvb_last_error(None).decode())
+        self.nrays = self.nreflections = 0
+
+    def close(self):
+        if self.handle:
+            self.lib.rvb_multi_destroy(self.handle)
+            self.handle = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise RvbError(rc, self.lib.rvb_multi_last_error(self.handle).decode())
+
+    def set_scene(self, scene):
+        triangles, vertices, surfaces = (np.ascontiguousarray(x) for x in scene)
+        self._check(self.lib.rvb_multi_set_scene(self.handle, _ptr(triangles), _u64(triangles.shape[0]), _ptr(vertices),
+                                                 _u64(vertices.shape[0]), _ptr(surfaces), _u64(surfaces.shape[0])))
+
+    def raytrace(self, mic, source, directions, nreflections, air):
+        d = np.ascontiguousarray(np.asarray(directions, np.float32).reshape(-1, 4))
+        self._check(self.lib.rvb_multi_set_directions(self.handle, _ptr(d), _u64(d.shape[0])))
+        self._check(self.lib.rvb_multi_trace(self.handle, _f3(mic), _f3(source), _u64(nreflections), _f8(air)))
+        self.nrays, self.nreflections = d.shape[0], int(nreflections)
+
+    def shard(self, index):
+        first, count = _u64(0), _u64(0)
+        self._check(self.lib.rvb_multi_context(self.handle, ctypes.c_int(index), None, ctypes.byref(first), ctypes.byref(count)))
+        return first.value, count.value
+
+    def used_rccl(self):
+        return bool(self.lib.rvb_multi_used_rccl(self.handle))
+
+    def get_raw_diffuse(self):
+        out = np.zeros(self.nrays * self.nreflections, dtype=IMPULSE)
+        self._check(self.lib.rvb_multi_get_diffuse(self.handle, _ptr(out)))
+        return out
+
+    def get_raw_images(self, remove_direct):
+        count = _u64(0)
+        self._check(self.lib.rvb_multi_get_images(self.handle, ctypes.c_int(int(remove_direct)), None, _u64(0), ctypes.byref(count)))
+        out = np.zeros(count.value, dtype=IMPULSE)
+        self._check(self.lib.rvb_multi_get_images(self.handle, ctypes.c_int(int(remove_direct)), _ptr(out), _u64(out.shape[0]), ctypes.byref(count)))
+        return out
+
+    def ir_speakers(self, mic, directions, coefficients, trim_predelay, sample_rate, mode, which=IR_ALL, remove_direct=False):
+        sp = make_speakers(directions, coefficients)
+        args = [self.handle, _f3(mic), _ptr(sp), _u64(sp.shape[0]), ctypes.c_int(which), ctypes.c_int(int(remove_direct)),
+                ctypes.c_int(int(trim_predelay)), ctypes.c_float(sample_rate), ctypes.c_int(mode)]
+        nbins = _u64(0)
+        self._check(self.lib.rvb_multi_ir_speakers(*args, None, _u64(0), ctypes.byref(nbins)))
+        out = np.zeros((sp.shape[0], 8, nbins.value), dtype=np.float32)
+        self._check(self.lib.rvb_multi_ir_speakers(*args, _ptr(out), _u64(nbins.value), ctypes.byref(nbins)))
+        return out
+
+    def ir_hrtf(self, mic, table, facing, up, trim_predelay, sample_rate, mode, which=IR_ALL, remove_direct=False):
+        t = np.ascontiguousarray(table, dtype=np.float32).reshape(-1)
+        assert t.shape[0] == 2 * 360 * 180 * 8
+        args = [self.handle, _f3(mic), _ptr(t), _f3(facing), _f3(up), ctypes.c_int(which), ctypes.c_int(int(remove_direct)),
+                ctypes.c_int(int(trim_predelay)), ctypes.c_float(sample_rate), ctypes.c_int(mode)]
+        nbins = _u64(0)
+        self._check(self.lib.rvb_multi_ir_hrtf(*args, None, _u64(0), ctypes.byref(nbins)))
+        out = np.zeros((2, 8, nbins.value), dtype=np.float32)
+        self._check(self.lib.rvb_multi_ir_hrtf(*args, _ptr(out), _u64(nbins.value), ctypes.byref(nbins)))
         return out

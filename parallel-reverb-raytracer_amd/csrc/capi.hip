@@ -83,7 +83,7 @@ struct rvb_ctx {
     bool ir_configured = false;
     AttenuationModel model;
     int which = RVB_IR_ALL;
-    DevBuf images, hrtf_table, acc, keys_a, keys_b, vals_a, vals_b, sort_temp, scratch_in, scratch_out, hist;
+    DevBuf images, hrtf_table, acc, keys_a, keys_b, vals_a, vals_b, sort_temp, scratch_in, scratch_out, hist, bin_starts;
     uint64_t nimages = 0;
     std::vector<rvb_impulse> images_host;
 
@@ -219,7 +219,7 @@ void rvb_destroy(rvb_ctx * ctx)
     if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
     for (DevBuf * b : {&ctx->nodes, &ctx->tris, &ctx->shade, &ctx->corners, &ctx->surfaces, &ctx->leafpos, &ctx->sort_keys, &ctx->sort_scratch, &ctx->sort_order, &ctx->group_temp, &ctx->directions_own, &ctx->impulses,
                        &ctx->early, &ctx->candidates, &ctx->small, &ctx->stamps, &ctx->images, &ctx->hrtf_table, &ctx->acc, &ctx->keys_a,
-                       &ctx->keys_b, &ctx->vals_a, &ctx->vals_b, &ctx->sort_temp, &ctx->scratch_in, &ctx->scratch_out, &ctx->hist,
+                       &ctx->keys_b, &ctx->vals_a, &ctx->vals_b, &ctx->sort_temp, &ctx->scratch_in, &ctx->scratch_out, &ctx->hist, &ctx->bin_starts,
                        &ctx->pair_geom, &ctx->pair_direct, &ctx->pair_range})
         b->release();
     for (rvb_ctx::CopyLane & l : ctx->copy_lanes) {
@@ -780,7 +780,11 @@ static int flatten_sum(rvb_ctx * ctx, const rvb_attenuated_impulse * d_in, uint6
     RVB_HIP(ctx, ctx->hist.ensure(bins * 8 * sizeof(float)));
     rvb_sort_pairs(ctx->sort_temp.p, ctx->sort_temp.cap, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(),
                    ctx->vals_a.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), n, key_bits_for(bins), ctx->stream);
-    rvb_launch_flat_ordered_sum(d_in, ctx->keys_b.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), n, bins, ctx->hist.as<float>(), ctx->stream);
+    RVB_HIP(ctx, ctx->bin_starts.ensure(bins * 4));
+    RVB_HIP(ctx, hipMemsetAsync(ctx->bin_starts.p, 0xFF, bins * 4, ctx->stream));
+    rvb_launch_bin_starts(ctx->keys_b.as<uint32_t>(), n, bins, ctx->bin_starts.as<uint32_t>(), ctx->stream);
+    rvb_launch_flat_ordered_sum(d_in, ctx->keys_b.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), ctx->bin_starts.as<uint32_t>(), n, bins,
+                                ctx->hist.as<float>(), ctx->stream);
     RVB_HIP(ctx, hipGetLastError());
     RVB_HIP(ctx, hipMemcpyAsync(out, ctx->hist.p, bins * 8 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1126,6 +1130,7 @@ int rvb_ir_accumulate(rvb_ctx * ctx, float predelay, float sample_rate, uint64_t
         // speaker channels keep the input time (kernel.cpp:530-533): one sorted list serves them all; the two ears of the
         // HRTF model shift the time differently (kernel.cpp:616-622) and get a list each
         const uint32_t lists = m.hrtf ? m.nchannels : 1u;
+        RVB_HIP(ctx, ctx->bin_starts.ensure(nbins * 4));
         for (uint32_t ch = 0; ch < lists; ++ch) {
             rvb_launch_bin_keys(m, ch, ir_diffuse(ctx), ndiffuse, 0, predelay, sample_rate, sentinel,
                                 ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), ctx->stream);
@@ -1133,8 +1138,10 @@ int rvb_ir_accumulate(rvb_ctx * ctx, float predelay, float sample_rate, uint64_t
                                 ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), ctx->stream);
             rvb_sort_pairs(ctx->sort_temp.p, ctx->sort_temp.cap, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(),
                            ctx->vals_a.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), n, bits, ctx->stream);
+            RVB_HIP(ctx, hipMemsetAsync(ctx->bin_starts.p, 0xFF, nbins * 4, ctx->stream));
+            rvb_launch_bin_starts(ctx->keys_b.as<uint32_t>(), n, nbins, ctx->bin_starts.as<uint32_t>(), ctx->stream);
             rvb_launch_ordered_sum(m, ch, m.hrtf ? 1u : m.nchannels, ir_diffuse(ctx), ndiffuse, ctx->images.as<rvb_impulse>(), nimages,
-                                   ctx->keys_b.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), n, nbins, hist, ctx->stream);
+                                   ctx->keys_b.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), ctx->bin_starts.as<uint32_t>(), n, nbins, hist, ctx->stream);
         }
         ctx->end_timing();
     } else {

@@ -93,13 +93,15 @@ void rvb_launch_bin_keys(const AttenuationModel & m, uint32_t channel, const rvb
                          float predelay, float sample_rate, uint32_t sentinel, uint32_t * keys, uint32_t * values, hipStream_t s);
 void rvb_launch_ordered_sum(const AttenuationModel & m, uint32_t first_channel, uint32_t nchannels, const rvb_impulse * diffuse,
                             uint64_t ndiffuse, const rvb_impulse * images, uint64_t nimages,
-                            const uint32_t * sorted_keys, const uint32_t * sorted_values, uint64_t n,
+                            const uint32_t * sorted_keys, const uint32_t * sorted_values, const uint32_t * starts, uint64_t n,
                             uint64_t nbins, float * hist, hipStream_t s);
+// starts[key] = first position of `key` in the sorted list (starts[] pre-filled with 0xFFFFFFFF by the caller, nbins entries)
+void rvb_launch_bin_starts(const uint32_t * sorted_keys, uint64_t n, uint64_t nbins, uint32_t * starts, hipStream_t s);
 // flattenImpulses of already attenuated impulses (rayverb.cpp:48-77): keys + ordered sum
 void rvb_launch_flat_keys(const rvb_attenuated_impulse * in, uint64_t n, float sample_rate, uint32_t * keys, uint32_t * values,
                           uint32_t * max_time_bits, hipStream_t s);
 void rvb_launch_flat_ordered_sum(const rvb_attenuated_impulse * in, const uint32_t * sorted_keys, const uint32_t * sorted_values,
-                                 uint64_t n, uint64_t nbins, float * out, hipStream_t s);
+                                 const uint32_t * starts, uint64_t n, uint64_t nbins, float * out, hipStream_t s);
 void rvb_launch_fix_predelay(rvb_attenuated_impulse * a, uint64_t n, float seconds, hipStream_t s);
 // stable sort of (key, value) pairs by key (device radix sort); temp storage managed by the caller
 size_t rvb_sort_temp_bytes(uint64_t n);

@@ -28,6 +28,12 @@ int device_from_env()
     return e ? std::atoi(e) : 0;
 }
 
+int devices_from_env()
+{
+    const char * e = std::getenv("RVB_DEVICES");
+    return e ? std::max(1, std::atoi(e)) : 1;
+}
+
 std::shared_ptr<rvb_ctx> make_context()
 {
     rvb_ctx * raw = nullptr;
@@ -359,6 +365,20 @@ Raytracer::Raytracer(unsigned long nreflections, SceneData sceneData, bool verbo
 
 void Raytracer::upload(std::vector<Triangle> & triangles, std::vector<cl_float3> & vertices, std::vector<Surface> & surfaces)
 {
+    const int ndev = devices_from_env();
+    if (ndev > 1) {
+        rvb_multi * raw = nullptr;
+        const int rc = rvb_multi_create(&raw, nullptr, ndev, 0);
+        if (rc != RVB_OK)
+            throw cl::Error(rc, rvb_last_error(nullptr));
+        multi_ = std::shared_ptr<rvb_multi>(raw, rvb_multi_destroy);
+        const int rc2 = rvb_multi_set_scene(raw, reinterpret_cast<const rvb_triangle *>(triangles.data()), triangles.size(),
+                                            reinterpret_cast<const rvb_float3 *>(vertices.data()), vertices.size(),
+                                            reinterpret_cast<const rvb_surface *>(surfaces.data()), surfaces.size());
+        if (rc2 != RVB_OK)
+            throw cl::Error(rc2, (std::string("rvb_multi_set_scene: ") + rvb_multi_last_error(raw)).c_str());
+        return;
+    }
     check(rvb_set_scene(context(), reinterpret_cast<const rvb_triangle *>(triangles.data()), triangles.size(),
                         reinterpret_cast<const rvb_float3 *>(vertices.data()), vertices.size(),
                         reinterpret_cast<const rvb_surface *>(surfaces.data()), surfaces.size()),
@@ -395,6 +415,13 @@ void Raytracer::raytrace(const cl_float3 & micpos, const cl_float3 & source, con
     const float air[8] = {(float) (0.001 * -0.1), (float) (0.001 * -0.2), (float) (0.001 * -0.5), (float) (0.001 * -1.1),
                           (float) (0.001 * -2.7), (float) (0.001 * -9.4), (float) (0.001 * -29.0), (float) (0.001 * -60.0)};
     nrays = directions.size();
+    if (multi_) {
+        int rc = rvb_multi_set_directions(multi_.get(), reinterpret_cast<const rvb_float3 *>(directions.data()), directions.size());
+        if (rc == RVB_OK) rc = rvb_multi_trace(multi_.get(), micpos.s, source.s, nreflections, air);     // blocking, every device at once
+        if (rc != RVB_OK)
+            throw cl::Error(rc, (std::string("rvb_multi_trace: ") + rvb_multi_last_error(multi_.get())).c_str());
+        return;
+    }
     check(rvb_set_directions(context(), reinterpret_cast<const rvb_float3 *>(directions.data()), directions.size()), "rvb_set_directions");
     check(rvb_trace(context(), micpos.s, source.s, nreflections, air, 0), "rvb_trace");
     check(rvb_synchronize(context()), "rvb_synchronize");     // the reference's raytrace() is blocking
@@ -404,6 +431,12 @@ void Raytracer::raytrace(const cl_float3 & micpos, const cl_float3 & source, con
 void Raytracer::fetchDiffuse(std::vector<Impulse> & out)
 {
     const size_t n = nrays * nreflections;
+    if (multi_) {                              // every device writes its slice of the array; no single device copy to remember
+        const int rc = rvb_multi_get_diffuse(multi_.get(), reinterpret_cast<rvb_impulse *>(out.data()));
+        if (rc != RVB_OK)
+            throw cl::Error(rc, (std::string("rvb_multi_get_diffuse: ") + rvb_multi_last_error(multi_.get())).c_str());
+        return;
+    }
     check(rvb_get_diffuse(context(), reinterpret_cast<rvb_impulse *>(out.data())), "rvb_get_diffuse");
     const void * d = nullptr;
     uint64_t count = 0;
@@ -417,6 +450,15 @@ void Raytracer::fetchDiffuse(std::vector<Impulse> & out)
 
 std::vector<Impulse> Raytracer::mergedImages(bool removeDirect)
 {
+    if (multi_) {
+        uint64_t count = 0;
+        int rc = rvb_multi_get_images(multi_.get(), removeDirect, nullptr, 0, &count);
+        std::vector<Impulse> ret(count);
+        if (rc == RVB_OK) rc = rvb_multi_get_images(multi_.get(), removeDirect, reinterpret_cast<rvb_impulse *>(ret.data()), count, &count);
+        if (rc != RVB_OK)
+            throw cl::Error(rc, (std::string("rvb_multi_get_images: ") + rvb_multi_last_error(multi_.get())).c_str());
+        return ret;
+    }
     uint64_t ncand = 0;
     check(rvb_get_image_candidates(context(), nullptr, 0, &ncand), "rvb_get_image_candidates");
     std::vector<rvb_image_candidate> cand(ncand);

@@ -216,6 +216,48 @@ int main()
             if (flat.size() != 1 || flat[0].size() != 8 || flat[0][0].size() != 3 || flat[0][3][0] != 0.25f || flat[0][3][2] != 0.5f)
                 { ++failures; std::printf("FAIL flattenImpulses\n"); }
         }
+        {   // The sequence of reference cmd/main.cpp:241-298 with the vectors handed from stage to stage (their device copies are
+            // reused) must give the bytes that the same stages give on COPIES of those vectors (fresh buffers: every stage uploads).
+            std::vector<cl_float3> dirs = getSeededDirections(3000, 7);
+            Raytracer tracer(16, TEST_OBJ, TEST_MAT, false);
+            const cl_float3 mic = {{0, 2, 0}}, src = {{0, 2, 2}};
+            tracer.raytrace(mic, src, dirs, false);
+            RaytracerResults results = tracer.getAllRaw(false);
+            const std::vector<Speaker> speakers = {Speaker{{{-1, 0, -1, 0}}, 0.5f}, Speaker{{{1, 0, -1, 0}}, 0.5f}};
+            auto same = [](const std::vector<std::vector<AttenuatedImpulse>> & x, const std::vector<std::vector<AttenuatedImpulse>> & y) {
+                if (x.size() != y.size()) return false;
+                for (size_t c = 0; c < x.size(); ++c) {
+                    if (x[c].size() != y[c].size()) return false;
+                    for (size_t i = 0; i < x[c].size(); ++i)
+                        if (std::memcmp(&x[c][i].volume, &y[c][i].volume, sizeof(VolumeType)) || x[c][i].time != y[c][i].time) return false;
+                }
+                return true;
+            };
+            auto resident = SpeakerAttenuator().attenuate(results, speakers);
+            RaytracerResults copy(results.impulses, results.mic);                  // same values, another buffer
+            auto uploaded = SpeakerAttenuator().attenuate(copy, speakers);
+            if (resident[0].size() != results.impulses.size() || !same(resident, uploaded)) { ++failures; std::printf("FAIL resident attenuate\n"); }
+            auto resident_copy = resident;                                         // fresh buffers: no device copies
+            fixPredelay(resident);
+            fixPredelay(resident_copy);
+            if (!same(resident, resident_copy)) { ++failures; std::printf("FAIL fixPredelay\n"); }
+            if (flattenImpulses(resident, 44100.0f) != flattenImpulses(resident_copy, 44100.0f)) { ++failures; std::printf("FAIL resident flatten\n"); }
+            // an edit of a handed-out vector must be seen (element 0 is part of the sample that guards the device copy)
+            results.impulses[0].volume.s[0] = 123.0f;
+            resident[1][0].volume.s[3] = -7.0f;
+            RaytracerResults edited(results.impulses, results.mic);
+            if (!same(SpeakerAttenuator().attenuate(results, speakers), SpeakerAttenuator().attenuate(edited, speakers)))
+                { ++failures; std::printf("FAIL edited results\n"); }
+            auto edited_att = resident;
+            if (flattenImpulses(resident, 44100.0f) != flattenImpulses(edited_att, 44100.0f)) { ++failures; std::printf("FAIL edited attenuated\n"); }
+            // HRTF attenuator through the same handover
+            tracer.raytrace(mic, src, dirs, false);
+            RaytracerResults again = tracer.getRawDiffuse();
+            RaytracerResults again_copy(again.impulses, again.mic);
+            const cl_float3 facing = {{0, 0, 1}}, up = {{0, 1, 0}};
+            if (!same(HrtfAttenuator().attenuate(again, facing, up), HrtfAttenuator().attenuate(again_copy, facing, up)))
+                { ++failures; std::printf("FAIL resident hrtf\n"); }
+        }
     } catch (const cl::Error & e) {
         std::printf("cl::Error %d: %s\n", e.err(), e.what());
         return 2;

@@ -1,0 +1,89 @@
+"""Several "devices" behind the C-ABI (rvb_multi_*, csrc/multi.hip) on the one GPU of the test box: the same GPU listed twice or
+three times gives real ray shards, real merges and the exact-mode chain; RCCL itself needs distinct devices, so its binding is
+exercised with a one-device communicator (RVB_MULTI_REHEARSE_RCCL).  More than one physical GPU is the driver's scaling run."""
+import numpy as np
+import pytest
+
+from parallel_reverb_raytracer_amd import scenes
+from parallel_reverb_raytracer_amd.dtypes import AIR_COEFFICIENTS
+
+pytestmark = pytest.mark.gpu
+
+SPEAKERS = ([(-1, 0, -1), (1, 0, -1)], [0.5, 0.5])
+
+
+def _same(a, b):
+    return all(np.array_equal(a[f], b[f]) for f in ("volume", "time")) and np.array_equal(a["position"][:, :3], b["position"][:, :3])
+
+
+@pytest.fixture(scope="module")
+def case():
+    scene, info = scenes.cathedral(12000)
+    return scene, info["mic"], info["source"], scenes.sphere_directions(6001, seed=11), 48     # 6001: shards of unequal size
+
+
+@pytest.fixture(scope="module")
+def single(case):
+    from parallel_reverb_raytracer_amd import capi
+    scene, mic, src, dirs, nrefl = case
+    ctx = capi.Context(0)
+    ctx.set_scene(scene)
+    ctx.raytrace(mic, src, dirs, nrefl, AIR_COEFFICIENTS)
+    images = ctx.get_raw_images(False)
+    out = {"diffuse": ctx.get_raw_diffuse(), "images": images}
+    ctx.ir_configure_speakers(mic, SPEAKERS[0], SPEAKERS[1], capi.IR_ALL, images)
+    out["speakers"] = ctx.ir_download(True, 44100.0, capi.IR_EXACT)
+    table = scenes.hrtf_synthetic_table()
+    ctx.ir_configure_hrtf(mic, table, (1.0, 0.0, 0.2), (0.0, 1.0, 0.0), capi.IR_ALL, images)
+    out["hrtf"] = ctx.ir_download(True, 44100.0, capi.IR_EXACT)
+    ctx.close()
+    return out
+
+
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0]])
+def test_shards_on_one_gpu_reproduce_a_single_context_bit_for_bit(case, single, devices):
+    from parallel_reverb_raytracer_amd import capi
+    scene, mic, src, dirs, nrefl = case
+    m = capi.MultiContext(devices)
+    try:
+        m.set_scene(scene)
+        m.raytrace(mic, src, dirs, nrefl, AIR_COEFFICIENTS)
+        ranges = [m.shard(i) for i in range(len(devices))]
+        assert ranges[0][0] == 0 and sum(c for _, c in ranges) == dirs.shape[0] and all(ranges[i + 1][0] == ranges[i][0] + ranges[i][1] for i in range(len(devices) - 1))
+        assert _same(m.get_raw_diffuse(), single["diffuse"])
+        assert _same(m.get_raw_images(False), single["images"])
+        # exact mode: the devices continue ONE serial sum in ray order
+        exact = m.ir_speakers(mic, SPEAKERS[0], SPEAKERS[1], True, 44100.0, capi.IR_EXACT)
+        assert exact.shape == single["speakers"].shape and np.array_equal(exact, single["speakers"])
+        table = scenes.hrtf_synthetic_table()
+        hrtf = m.ir_hrtf(mic, table, (1.0, 0.0, 0.2), (0.0, 1.0, 0.0), True, 44100.0, capi.IR_EXACT)
+        assert hrtf.shape == single["hrtf"].shape and np.array_equal(hrtf, single["hrtf"])
+        # fast mode: float atomics per shard, then the sum over the shards (peer copies here: RCCL refuses one GPU twice)
+        fast = m.ir_speakers(mic, SPEAKERS[0], SPEAKERS[1], True, 44100.0, capi.IR_FAST)
+        assert not m.used_rccl()
+        band_max = np.abs(exact).max(axis=2, keepdims=True)
+        assert (np.abs(fast.astype(np.float64) - exact) <= 1e-5 * band_max).all() and fast.any()
+        # diffuse only / images only add up to the same bins
+        only_images = m.ir_speakers(mic, SPEAKERS[0], SPEAKERS[1], False, 44100.0, capi.IR_EXACT, which=capi.IR_IMAGES)
+        assert only_images.any() and only_images.shape[2] <= exact.shape[2]
+    finally:
+        m.close()
+
+
+def test_rccl_all_reduce_is_bound_and_runs(case, single):
+    """librccl.so loaded at run time, one communicator over the device list, ncclAllReduce in place on the histogram: with one
+    device the sum is the identity, so the result must equal the plain fast-mode histogram up to its own atomics order."""
+    from parallel_reverb_raytracer_amd import capi
+    scene, mic, src, dirs, nrefl = case
+    m = capi.MultiContext([0], flags=capi.MULTI_REHEARSE_RCCL)
+    try:
+        m.set_scene(scene)
+        m.raytrace(mic, src, dirs, nrefl, AIR_COEFFICIENTS)
+        fast = m.ir_speakers(mic, SPEAKERS[0], SPEAKERS[1], True, 44100.0, capi.IR_FAST)
+        assert m.used_rccl(), "RCCL was not used: librccl.so missing or the communicator could not be created"
+        exact = single["speakers"]
+        band_max = np.abs(exact).max(axis=2, keepdims=True)
+        assert fast.shape == exact.shape and (np.abs(fast.astype(np.float64) - exact) <= 1e-5 * band_max).all()
+        assert np.array_equal(m.ir_speakers(mic, SPEAKERS[0], SPEAKERS[1], True, 44100.0, capi.IR_EXACT), exact)
+    finally:
+        m.close()

@@ -11,7 +11,22 @@ import sys
 tag = sys.argv[1]
 out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
 SHORT = ["path_kernel", "image_kernel", "shadow_kernel", "histogram_fast_kernel", "histogram_transpose_kernel", "attenuate_kernel",
-         "time_range_kernel", "radix_sort_onesweep_iteration", "radix_sort_onesweep_global_offsets"]
+         "time_range_kernel", "bin_keys_kernel", "ordered_sum_kernel", "radix_sort_onesweep_iteration", "radix_sort_onesweep_global_offsets"]
+
+# VALU issue model: dynamic instruction mix (per-class PMC counters) x measured issue cost per class (tools/inst_probe.hip at
+# 8 waves per SIMD, ns per wave-instruction per SIMD, parsed from profiles/<tag>_inst_probe.log by tools/inst_costs.py)
+CLASSES = {
+    "f32_add_mul_fma": (["SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32"], ["add_f32", "mul_f32", "v_fma_f32"]),
+    "f32_transcendental": (["SQ_INSTS_VALU_TRANS_F32"], ["rcp", "sqrt"]),
+    "f64_add_mul_fma": (["SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64"], ["add_f64", "mul_f64", "fma_f64"]),
+    "f64_transcendental": (["SQ_INSTS_VALU_TRANS_F64"], ["rcp_f64"]),
+    "convert": (["SQ_INSTS_VALU_CVT"], ["cvt_f16", "cvt_f32_f64", "cvt_f64_f32", "cvt_i32_f64"]),
+    "int32": (["SQ_INSTS_VALU_INT32"], ["and_or", "lshl_add", "mul_lo", "mul_u24", "bcnt"]),
+    "int64": (["SQ_INSTS_VALU_INT64"], ["cmp_u64"]),
+    # everything the class counters do not name: min / max / compare / select / DPP and plain moves
+    "other": ([], ["min", "max3", "cmp", "cndmask_sgpr", "mov_dpp", "min_dpp", "perm", "mov"]),
+}
+SIMDS = 1024
 
 
 def short(name):
@@ -65,6 +80,29 @@ for s, c in pmc.items():
         # SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES count quad-cycles (MI355X_MICROARCH.md "s_memtime tick vs SQ PMC units")
         c["valu_active_share_of_wave_cycles"] = c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else None
         c["wait_any_share_of_wave_cycles"] = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") and "SQ_WAIT_ANY" in c else None
+costs = {}
+try:
+    costs = json.load(open(os.path.join(out, tag + "_inst_costs.json")))["8"]
+except (OSError, KeyError, ValueError):
+    pass
+for s_, c in pmc.items():
+    if "SQ_THREAD_CYCLES_VALU" in c and c.get("SQ_ACTIVE_INST_VALU"):
+        # rocprofiler's VALUUtilization: active lanes per VALU instruction / 64
+        c["valu_lane_utilisation"] = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0)
+    if costs and "SQ_INSTS_VALU" in c and "SQ_INSTS_VALU_INT32" in c:
+        mix, named, model_ns = {}, 0.0, 0.0
+        for name, (counters, probes) in CLASSES.items():
+            if not counters:
+                continue
+            n = sum(c.get(k, 0.0) for k in counters)
+            mix[name] = n
+            named += n
+        mix["other"] = max(0.0, c["SQ_INSTS_VALU"] - named)
+        for name, n in mix.items():
+            cost = sum(costs[p] for p in CLASSES[name][1]) / len(CLASSES[name][1])
+            model_ns += n * cost / SIMDS
+        c["valu_mix"] = mix
+        c["valu_issue_model_ms"] = model_ns * 1e-6
 irs = pmc.get("path_kernel", {}).get("_launches", 0)
 for c in pmc.values():                                   # a kernel launched more than once per IR (binning: diffuse + images)
     if "hbm_bytes_per_launch" in c and irs:
