@@ -134,7 +134,7 @@ def test_c2_final_ir_exact_mode_equals_oracle_chain_and_fast_mode_is_within_tole
     assert report["max_abs_err_over_band_max"] <= 1e-5
 
 
-def test_c4_atrium_262k_triangles_256_bounces(ctx, oracle):
+def test_c4_atrium_262k_triangles_256_bounces_small_ray_set(ctx, oracle):
     scene, info = scenes.atrium(262000)
     assert scene[0].shape[0] > 250000
     nrays, nrefl = 4096, 256
@@ -145,6 +145,129 @@ def test_c4_atrium_262k_triangles_256_bounces(ctx, oracle):
     sample = np.array([0, 17, 1023, 4095])
     want, _, _ = oracle.raytrace(scene, info["mic"], info["source"], dirs[sample], nrefl, AIR_COEFFICIENTS)
     assert _same(got[sample].reshape(-1), want)
+
+
+def test_c3_per_gpu_share_125k_rays_at_a_ray_offset(ctx, oracle):
+    """BASELINE config C3 = 1M rays x 128 over 8 GPUs: what ONE of the eight ranks runs — its contiguous 125 000-ray shard of
+    the global seeded set (here rank 5's: ray_offset 625 000), traced as one resident round of waves (125 000 rays = 7 813
+    workgroups of 16 on 8 192 wave slots... one round at 8 waves per SIMD).  Sampled rays against brute force, image-source
+    candidates carrying GLOBAL ray numbers, run-to-run determinism, and the exact-mode histogram of the shard against the
+    oracle chain on a prefix small enough for the CPU."""
+    from parallel_reverb_raytracer_amd import capi, distributed
+    scene, info = scenes.cathedral(75000)
+    mic, src = info["mic"], info["source"]
+    world, rank, nrefl = 8, 5, 128
+    first, nrays = distributed.shard_range(1000000, rank, world)
+    assert (first, nrays) == (625000, 125000)
+    dirs = scenes.sphere_directions(nrays, seed=1, first=first)
+    assert np.array_equal(dirs[:7], scenes.sphere_directions(1000000, seed=1)[first:first + 7])      # the shard IS a slice of the global set
+    ctx.set_scene(scene)
+    ctx.set_directions(dirs)
+    ctx.trace(mic, src, nrefl, AIR_COEFFICIENTS, ray_offset=first)
+    full = ctx.get_raw_diffuse().reshape(nrays, nrefl)
+    cands = ctx.get_image_candidates()
+    assert cands.shape[0] == 0 or (cands["ray"].min() >= first and cands["ray"].max() < first + nrays)
+    sample = np.sort(np.random.default_rng(9).choice(nrays, 96, replace=False))
+    want, image, index = oracle.raytrace(scene, mic, src, dirs[sample], nrefl, AIR_COEFFICIENTS)
+    assert _same(full[sample].reshape(-1), want)
+    idx = index.reshape(len(sample), 10)
+    for k, ray in enumerate(sample):
+        mine = cands[cands["ray"] == first + ray]
+        slots = np.nonzero(idx[k, 1:])[0] + 1
+        assert np.array_equal(mine["slot"], slots) and np.array_equal(mine["index"], idx[k, slots])
+    crc = _crc(full)
+    # the shard's histogram as rank 5 forms it (diffuse impulses only; rank 0 adds the merged images): exact mode == serial sum
+    ctx.ir_configure_speakers(mic, [(-1, 0, -1), (1, 0, -1)], [0.5, 0.5], capi.IR_DIFFUSE, None)
+    lo, hi = ctx.ir_time_range()
+    exact = ctx.ir_download(True, 44100.0, capi.IR_EXACT)
+    chans = [oracle.attenuate_speaker(mic, full.reshape(-1), d, 0.5) for d in ((-1, 0, -1), (1, 0, -1))]
+    pd = oracle.find_predelay(chans)
+    assert pd == lo
+    for ch in range(2):
+        oracle.fix_predelay(chans[ch], pd)
+        flat = oracle.flatten(chans[ch], 44100.0)
+        assert np.array_equal(exact[ch][:, :flat.shape[1]], flat) and not exact[ch][:, flat.shape[1]:].any()
+    ctx.trace(mic, src, nrefl, AIR_COEFFICIENTS, ray_offset=first)
+    assert _crc(ctx.get_raw_diffuse()) == crc
+
+
+def test_c4_atrium_100k_rays_x_256_bounces(ctx, oracle):
+    """BASELINE config C4 at its full size: 100 000 rays x 256 bounces on the 263k-triangle atrium stand-in (1.6 GB of impulses):
+    sampled rays against brute force over all triangles, shard invariance, determinism."""
+    scene, info = scenes.atrium(262000)
+    mic, src = info["mic"], info["source"]
+    nrays, nrefl = 100000, 256
+    dirs = scenes.sphere_directions(nrays, seed=4)
+    ctx.set_scene(scene)
+    ctx.raytrace(mic, src, dirs, nrefl, AIR_COEFFICIENTS)
+    full = ctx.get_raw_diffuse().reshape(nrays, nrefl)
+    assert ctx.executed_bounces() > 0.9 * nrays * nrefl
+    sample = np.sort(np.random.default_rng(6).choice(nrays, 40, replace=False))       # 10 k bounces x 263 k triangles
+    want, _, _ = oracle.raytrace(scene, mic, src, dirs[sample], nrefl, AIR_COEFFICIENTS)
+    assert _same(full[sample].reshape(-1), want)
+    crc_halves = [_crc(full[:nrays // 2]), _crc(full[nrays // 2:])]
+    images_full = ctx.get_raw_images(False)
+    del full
+    from parallel_reverb_raytracer_amd import capi
+    got, cands = [], []
+    for first in (0, nrays // 2):
+        ctx.set_directions(dirs[first:first + nrays // 2])
+        ctx.trace(mic, src, nrefl, AIR_COEFFICIENTS, ray_offset=first)
+        got.append(_crc(ctx.get_raw_diffuse()))
+        cands.append(ctx.get_image_candidates())
+    assert got == crc_halves
+    assert _same(capi.merge_images(np.concatenate(cands[::-1]), ctx.get_direct(), False), images_full)
+
+
+def test_c5_per_gpu_share_8_pairs_x_100k_rays_hrtf_four_pairs_per_launch(ctx, oracle):
+    """BASELINE config C5 = 64 (source, listener) pairs over 8 GPUs, HRTF: ONE rank's share — 8 pairs x 100 000 rays x 128 —
+    through generate_pair_irs with four pairs per launch (400 000 rays per launch, launches alternating between two contexts),
+    in the benchmarked exact mode: every pair's [2][8][nbins] histogram must be bit-identical to that pair traced and binned
+    alone; sampled rays of two pairs against brute force; the float-atomic mode within the stated tolerance of the exact one."""
+    import torch
+    from parallel_reverb_raytracer_amd import capi, distributed
+    scene, _ = scenes.concert_hall(30000)
+    src, mic = scenes.source_mic_pairs(64, seed=0)
+    table = scenes.hrtf_synthetic_table()
+    nrays, nrefl = 100000, 128
+    first, count = distributed.shard_range(64, 3, 8)                    # rank 3 of 8: pairs 24 .. 31
+    assert count == 8
+    pairs = list(range(first, first + count))
+    dirs = scenes.sphere_directions(nrays, seed=1)
+    other = capi.Context(0)
+    try:
+        for c in (ctx, other):
+            c.set_scene(scene)
+            c.set_directions(dirs)
+        device = torch.device("cuda", 0)
+
+        def model_for(i):
+            p = pairs[i]
+            facing = src[p] - mic[p]
+            return distributed.HrtfModel(table, facing / np.linalg.norm(facing), (0, 1, 0))
+
+        batched = distributed.generate_pair_irs([ctx, other], [(mic[p], src[p]) for p in pairs], nrefl, AIR_COEFFICIENTS, model_for,
+                                                44100.0, device=device, mode=capi.IR_EXACT, pairs_per_launch=4)
+        assert sorted(batched) == list(range(count))
+        rng = np.random.default_rng(12)
+        for k, p in enumerate(pairs):
+            hist, info = distributed.generate_ir(ctx, mic[p], src[p], nrefl, AIR_COEFFICIENTS, model=model_for(k), sample_rate=44100.0,
+                                                 trim_predelay=True, mode=capi.IR_EXACT, device=device)
+            got, got_info = batched[k]
+            assert got_info["nbins"] == info["nbins"] and got_info["images"] == info["images"]
+            assert torch.equal(got, hist) and bool(hist.any())
+            if k in (0, 5):
+                sample = np.sort(rng.choice(nrays, 48, replace=False))
+                want, _, _ = oracle.raytrace(scene, mic[p], src[p], dirs[sample], nrefl, AIR_COEFFICIENTS)
+                assert _same(ctx.get_raw_diffuse().reshape(nrays, nrefl)[sample].reshape(-1), want)
+            if k == 7:          # pair 31: ten million audible impulses (pair 24's microphone sits in a corner most shadow rays cannot reach)
+                fast, _ = distributed.generate_ir(ctx, mic[p], src[p], nrefl, AIR_COEFFICIENTS, model=model_for(k), sample_rate=44100.0,
+                                                  trim_predelay=True, mode=capi.IR_FAST, device=device)
+                report = fast_vs_exact_report(fast.cpu().numpy(), hist.cpu().numpy())
+                print("fast_vs_exact at C5 (HRTF):", report)
+                assert report["max_abs_err_over_band_max"] <= 1e-5 and report["band_bins_differing"] > 1000
+    finally:
+        other.close()
 
 
 def test_c5_hall_source_listener_pairs_hrtf(ctx, oracle):
