@@ -15,7 +15,7 @@
 //             half line per node visit with a single 16-byte load each.  Boxes only prune, so their
 //             precision does not touch results; halving node bytes halves the L1 (TCP) traffic.
 //   tris    : BvhTri[],     48 B, in leaf order: v0, e0, e1 (edges precomputed), original index
-//   shade   : TriShade[],   16 B, by ORIGINAL triangle index: unit normal + surface index
+//   shade   : TriShade[],   32 B, by ORIGINAL triangle index: unit normal + surface index + own-plane skip
 //   verts9  : TriCorners[], 48 B, by ORIGINAL triangle index: the three vertices (image-source)
 #pragma once
 
@@ -46,18 +46,21 @@ struct BvhTri {                     // 48 B
     uint32_t pad;
 };
 
-struct TriShade { float n[3]; uint32_t surface; };     // 16 B
 struct TriCorners { float v[9]; float pad[3]; };       // 48 B
 
-// Own-plane skip (by ORIGINAL triangle index).  A ray that STARTS on triangle T (a reflected ray, or the shadow ray of the
-// same point) cannot hit — with a distance above EPSILON — any triangle that lies in T's plane, provided it leaves the plane
-// steeply enough: such a triangle's Möller–Trumbore distance is (offset of the origin from the plane) / |cos|, which is
-// rounding noise divided by |cos|.  `ref` is the child reference of the LARGEST subtree around T whose triangles are all
-// coplanar with T (RVB_BVH_EMPTY if there is none); the traversal rejects that child without visiting it when
-//      |dot(unit normal of T, direction)|  >  a + b * (length of the ray segment that ended on T)
-// a, b come from the error analysis in bvh_build.hip (analyse_planes).  Without it, every query first descends into the
-// wall it starts on (the padded boxes around its origin cannot be culled): 7 of the 15.5 node visits per bounce at C2.
-struct TriSkip { uint32_t ref; float a; float b; uint32_t group; };     // 16 B
+// Shading record by ORIGINAL triangle index, 32 B = two 16-byte loads from one half line: unit normal + surface, and the
+// own-plane skip of the triangle.
+//
+// Own-plane skip.  A ray that STARTS on triangle T (a reflected ray, or the shadow ray of the same point) cannot hit — with a
+// distance above EPSILON — any triangle that lies in T's plane, provided it leaves the plane steeply enough: such a triangle's
+// Möller–Trumbore distance is (offset of the origin from the plane) / |cos|, i.e. rounding noise divided by |cos|.  `skip_ref`
+// is the child reference of the LARGEST subtree around T whose triangles are all coplanar with T (RVB_BVH_EMPTY if there is
+// none; the builder makes every plane patch a subtree of its own so that a wall is one such child); the traversal rejects that
+// child without visiting it when
+//      |dot(unit normal of T, direction)|  >  skip_a + skip_b * (length of the ray segment that ended on T)
+// skip_a, skip_b come from the error analysis in bvh_build.hip (assign_skips).  Without the skip every query first descends
+// into the wall it starts on (the padded boxes around its origin cannot be culled).
+struct TriShade { float n[3]; uint32_t surface; uint32_t skip_ref; float skip_a; float skip_b; uint32_t group; };     // 32 B
 
 struct BuiltScene {
     std::vector<BvhNode> nodes;
@@ -65,7 +68,6 @@ struct BuiltScene {
     std::vector<TriShade> shade;
     std::vector<TriCorners> corners;
     std::vector<uint32_t> leafpos;  // by ORIGINAL triangle index: position in `tris` (spatially coherent), 0xFFFFFFFF if dropped
-    std::vector<TriSkip> skip;      // by ORIGINAL triangle index
     uint32_t depth = 0;             // levels of 4-wide nodes
     uint32_t stack_need = 0;        // worst-case traversal stack entries (<= RVB_BVH_STACK)
     float pad = 0.0f;               // box padding actually used (metres)

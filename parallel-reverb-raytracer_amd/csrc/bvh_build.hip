@@ -251,8 +251,9 @@ struct Builder {
 //      c > C + (A + B t) / EPSILON,   A = 6 delta + G + 32 eps kappa L + 1.74 eps maxabs,  B = 16 eps kappa + 4 eps,
 //      G = max over the group of 34 eps (L' + 0.02) kappa',  C = 2 theta + max 16 eps kappa' + 8 eps,
 // with c = |dot(stored unit normal of T, d)| as the kernels compute it.  Constants carry a factor 2 over the derivation and the
-// final inequality another 1e-4 relative; TriSkip::a = C + A (1 + 1e-4) / EPSILON (at least 0.01), b = B (1 + 1e-4) / EPSILON.
+// final inequality another 1e-4 relative; TriShade::skip_a = C + A (1 + 1e-4) / EPSILON (at least 0.01), skip_b = B (1 + 1e-4) / EPSILON.
 // tools/travsim.cpp (TRAVSIM_VERIFY) checks the rule against brute force on the host, the GPU parity tests on the device.
+// TriSkip fields live in TriShade (bvh.h).
 struct PlaneGroup {
     double n[3] = {0, 0, 1}, p[3] = {0, 0, 0};      // reference plane (that of the group's largest triangle): unit normal, point
     double area = -1.0, delta = 0.0, theta = 0.0, g = 0.0, d = 0.0;
@@ -368,12 +369,13 @@ void find_planes(const BuiltScene & out, const std::vector<Prim> & prims, Planes
         pg.ok = pg.delta <= 1e-5 && pg.theta <= 1e-3;
 }
 
-// After the 4-wide tree exists: TriSkip per triangle (reference of the highest child slot whose triangles all belong to the
+// After the 4-wide tree exists: the skip fields of TriShade per triangle (reference of the highest child slot whose triangles all belong to the
 // triangle's plane group; a, b of the rule above).
 void assign_skips(BuiltScene & out, const Planes & pl, float maxabs)
 {
     const double eps = 0x1p-24, EPS = (double) RVB_EPSILON;
     const std::vector<uint32_t> & gid = pl.gid;
+    if (gid.empty()) return;                                  // plane analysis switched off
     // per child slot: the group all triangles below share (MIXED = none); children have larger node indices than parents
     const uint32_t MIXED = 0xFFFFFFFFu;
     std::vector<uint32_t> node_group(out.nodes.size() * 4, MIXED);
@@ -419,7 +421,7 @@ void assign_skips(BuiltScene & out, const Planes & pl, float maxabs)
                 below.pop_back();
                 if (r & RVB_BVH_LEAF) {
                     const uint32_t first = r & 0x0FFFFFFFu, count = ((r >> 28) & 7u) + 1u;
-                    for (uint32_t j = 0; j < count; ++j) out.skip[out.tris[first + j].index].ref = ref;
+                    for (uint32_t j = 0; j < count; ++j) out.shade[out.tris[first + j].index].skip_ref = ref;
                 } else {
                     for (int c = 0; c < 4; ++c)
                         if (out.nodes[r >> RVB_BVH_NODE_SHIFT].c[c].ref != RVB_BVH_EMPTY) below.push_back(out.nodes[r >> RVB_BVH_NODE_SHIFT].c[c].ref);
@@ -428,18 +430,18 @@ void assign_skips(BuiltScene & out, const Planes & pl, float maxabs)
         }
     }
     for (const BvhTri & t : out.tris) {
-        TriSkip & sk = out.skip[t.index];
+        TriShade & sk = out.shade[t.index];
         sk.group = gid[t.index];
-        if (sk.ref == RVB_BVH_EMPTY) continue;
+        if (sk.skip_ref == RVB_BVH_EMPTY) continue;
         const PlaneGroup & pg = pl.groups[gid[t.index]];
         const TriGeo & g = pl.geo[t.index];
         const double A = 6.0 * pg.delta + pg.g + 32.0 * eps * g.kappa * g.L + 1.74 * eps * (double) maxabs;
         const double B = 16.0 * eps * g.kappa + 4.0 * eps;
         const double C = 2.0 * pg.theta + pg.d + 8.0 * eps;
         const double a = std::max(0.01, C + A * (1.0 + 1e-4) / EPS), b = B * (1.0 + 1e-4) / EPS;
-        sk.a = std::nextafterf((float) a, 2.0f);           // rounded up to binary32
-        sk.b = std::nextafterf((float) b, 2.0f);
-        if (!(a < 1.0)) sk.ref = RVB_BVH_EMPTY;            // |cos| never exceeds 1: no ray qualifies
+        sk.skip_a = std::nextafterf((float) a, 2.0f);      // rounded up to binary32
+        sk.skip_b = std::nextafterf((float) b, 2.0f);
+        if (!(a < 1.0)) sk.skip_ref = RVB_BVH_EMPTY;       // |cos| never exceeds 1: no ray qualifies
     }
 }
 
@@ -489,6 +491,7 @@ std::string rvb_build_scene(const rvb_triangle * triangles, uint64_t ntriangles,
         v3 n = verts_normal(tv);                     // reference kernel.cpp:109-127
         out.shade[i].n[0] = n.x; out.shade[i].n[1] = n.y; out.shade[i].n[2] = n.z;
         out.shade[i].surface = (uint32_t) t.surface;
+        out.shade[i].skip_ref = RVB_BVH_EMPTY; out.shade[i].skip_a = 2.0f; out.shade[i].skip_b = 0.0f; out.shade[i].group = 0xFFFFFFFFu;
         float c9[9] = {p0.x, p0.y, p0.z, p1.x, p1.y, p1.z, p2.x, p2.y, p2.z};
         std::memcpy(out.corners[i].v, c9, sizeof(c9));
         std::memset(out.corners[i].pad, 0, sizeof(out.corners[i].pad));
@@ -518,9 +521,8 @@ std::string rvb_build_scene(const rvb_triangle * triangles, uint64_t ntriangles,
     }
 
     const uint32_t nprims = (uint32_t) b.prims.size();
-    out.skip.assign(ntriangles, TriSkip{RVB_BVH_EMPTY, 0.0f, 0.0f, 0xFFFFFFFFu});
     Planes planes;
-    static const bool plane_skip = getenv("RVB_PLANE_SKIP") && getenv("RVB_PLANE_SKIP")[0] == '1';     // (experiment: the kernels do not use TriSkip yet)
+    static const bool plane_skip = !(getenv("RVB_PLANE_SKIP") && getenv("RVB_PLANE_SKIP")[0] == '0');
     // (0 = no units; a unit is larger than a leaf, so a leaf never holds part of one)
     static const uint32_t unit_min_env = getenv("RVB_PLANE_UNIT_MIN") ? (uint32_t) atoi(getenv("RVB_PLANE_UNIT_MIN")) : 8u;
     static const uint32_t unit_min = unit_min_env == 0 ? 0u : std::max(unit_min_env, (uint32_t) RVB_BVH_MAX_LEAF + 1u);

@@ -137,9 +137,11 @@ __device__ __forceinline__ uint32_t quad_ballot(bool pred)
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ half2_t as_half2(uint32_t u) { return __builtin_bit_cast(half2_t, u); }
 
+// `skip`: a child reference the query must not enter (the own-plane subtree of the triangle the ray starts on, TriShade in bvh.h;
+// RVB_BVH_EMPTY = none, which doubles as the test for an empty slot).
 __device__ __forceinline__ bool slab(const uint4 n, const float ix, const float iy, const float iz,
                                      const float oix, const float oiy, const float oiz,
-                                     const float limit, const float neg_cull, float & tn)
+                                     const float limit, const float neg_cull, const uint32_t skip, float & tn)
 {
     const half2_t h0 = as_half2(n.x), h1 = as_half2(n.y), h2 = as_half2(n.z);   // (lo.x, lo.y) (lo.z, hi.x) (hi.y, hi.z)
     const float tx0 = fmaf((float) h0.x, ix, -oix), tx1 = fmaf((float) h1.y, ix, -oix);
@@ -153,7 +155,7 @@ __device__ __forceinline__ bool slab(const uint4 n, const float ix, const float 
     asm("v_min_f32 %0, %1, %2" : "=v"(zf) : "v"(zf), "v"(limit));
     tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), zn);
     const float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), zf);
-    return tn <= tf && n.w != RVB_BVH_EMPTY;
+    return tn <= tf && n.w != RVB_BVH_EMPTY && n.w != skip;
 }
 
 // Closest hit (ANY = false): the brute-force winner of reference kernel.cpp:167-192.
@@ -203,7 +205,7 @@ __device__ __forceinline__ void traverse_jobs(const SceneDev & sc, uint32_t * __
             const uint4 n = *reinterpret_cast<const uint4 *>(node_base + (ref | child_off));
             const float limit = fmaf(best_t, cull_scale, sc.cull_abs);
             float tn;
-            const bool ok = slab(n, ix, iy, iz, oix, oiy, oiz, limit, neg_cull, tn);
+            const bool ok = slab(n, ix, iy, iz, oix, oiy, oiz, limit, neg_cull, job.skip_ref(), tn);
             const uint32_t cref = n.w;
             // key = entry distance (two mantissa bits traded for the lane id): the quad minimum names
             // the nearest hit child and the lane that owns it in two DPP steps
@@ -377,7 +379,7 @@ __device__ __forceinline__ void traverse_jobs_vote(const SceneDev & sc, uint32_t
 #endif
                 const float limit = fmaf(__uint_as_float((uint32_t) (best_key >> 32)), cull_scale, sc.cull_abs);
                 float tn;
-                const bool ok = slab(n, ix, iy, iz, oix, oiy, oiz, limit, neg_cull, tn);
+                const bool ok = slab(n, ix, iy, iz, oix, oiy, oiz, limit, neg_cull, job.skip_ref(), tn);
                 const uint32_t cref = n.w;
                 const uint32_t key = ok ? ((__float_as_uint(fmaxf(tn, 0.0f)) & ~3u) | c) : NONE;
                 uint32_t kmin = min(key, dpp_u<QP_SWAP1>(key));
@@ -440,6 +442,8 @@ struct OneShotJob {
     float tmax;
     bool pending, hit;
     Hit result;
+    uint32_t skip;
+    __device__ __forceinline__ uint32_t skip_ref() const { return skip; }
     __device__ __forceinline__ bool next(v3 & o_, v3 & d_, float & tmax_)
     {
         if (!pending) return false;
@@ -452,9 +456,9 @@ struct OneShotJob {
 
 template <bool ANY>
 __device__ __forceinline__ bool traverse_quad(const SceneDev & sc, const v3 o, const v3 d, const float tmax,
-                                              uint32_t * __restrict__ stack, Hit & hit)
+                                              uint32_t * __restrict__ stack, Hit & hit, const uint32_t skip = RVB_BVH_EMPTY)
 {
-    OneShotJob job = {o, d, tmax, true, false, {0.0f, NONE}};
+    OneShotJob job = {o, d, tmax, true, false, {0.0f, NONE}, skip};
     traverse_jobs<ANY>(sc, stack, job);
     hit = job.result;
     return job.hit;
@@ -483,7 +487,7 @@ __device__ __forceinline__ bool traverse_lane(const SceneDev & sc, const v3 o, c
             for (int c = 0; c < 4; ++c) {
                 const uint4 nc = n[c];
                 float tn;
-                const bool ok = slab(nc, ix, iy, iz, oix, oiy, oiz, limit, neg_cull, tn);
+                const bool ok = slab(nc, ix, iy, iz, oix, oiy, oiz, limit, neg_cull, RVB_BVH_EMPTY, tn);
                 key[c] = ok ? tn : __builtin_inff();
                 cref[c] = ok ? nc.w : NONE;
             }
@@ -536,7 +540,7 @@ __device__ __forceinline__ v3 ld3(const float * p) { return mk3(p[0], p[1], p[2]
 // Work record left by path_kernel in impulses[ray*nrefl + bounce] (64 B; quad lane c stores chunk c):
 //   chunk 0,1  newVol = -volume * specular                        (kernel.cpp:461)
 //   chunk 2    intersection.xyz, DIFF = |dot(normal, dir)|         (kernel.cpp:459, :478)
-//   chunk 3    newDist, surface index, triangle index, 1 = valid   (kernel.cpp:460)
+//   chunk 3    newDist, own-plane threshold of the shadow ray, triangle index, pair + 1 = valid   (kernel.cpp:460)
 // shadow_kernel turns it into the final Impulse in place.
 // One ray's bounce chain as a Job: next() hands out the current ray, done() shades the hit
 // (kernel.cpp:459-461, :478), stores the work record and reflects (kernel.cpp:492-501).
@@ -572,7 +576,10 @@ struct PathJob {
     bool alive;
     lds_float4_ptr surf_lds;             // the surface table staged in LDS (stage_surfaces); unused when !SURF_LDS
     uint32_t pair_tag;                   // (source, microphone) pair of this ray + 1: what marks its work records as valid
+    uint32_t skip;                       // own-plane subtree of the triangle the current segment starts on (TriShade, bvh.h)
+    bool unit;                           // the ray's direction has unit length (the own-plane rule is derived for |d| = 1)
 
+    __device__ __forceinline__ uint32_t skip_ref() const { return skip; }
     __device__ __forceinline__ bool next(v3 & o_, v3 & d_, float & tmax)
     {
         if (!alive || index >= a.nreflections)
@@ -588,7 +595,8 @@ struct PathJob {
             alive = false;
             return;
         }
-        const float4 sh = reinterpret_cast<const float4 *>(a.scene.shade)[h.tri];
+        const float4 * shade = reinterpret_cast<const float4 *>(a.scene.shade + h.tri);       // 32 B: normal + surface, own-plane skip
+        const float4 sh = shade[0], sk = shade[1];
         const v3 normal = mk3(sh.x, sh.y, sh.z);
         const uint32_t surface = __float_as_uint(sh.w);
         // the specular row hangs off a dependent load (triangle -> surface -> row): from LDS it costs ~64 cycles
@@ -601,10 +609,20 @@ struct PathJob {
         const float new_dist = distance + h.t;                       // kernel.cpp:460
         vol = make_float4(-vol.x * sp.x, -vol.y * sp.y, -vol.z * sp.z, -vol.w * sp.w);   // kernel.cpp:461
         const float diff = fabsf(dot3(normal, d));                   // kernel.cpp:478
+        // Own-plane skip (bvh.h): the rays that START at p — the reflected ray and the shadow ray — may pass over the subtree of
+        // this triangle's plane patch when they leave the plane steeply enough: |cos| > skip_a + skip_b * (segment length).  The
+        // reflected ray's |cos| is `diff` (reflection keeps it); the shadow kernel compares its own against the threshold the
+        // record carries (+inf: no skip).
+        const float threshold = unit ? fmaf(sk.z, h.t, sk.y) : __builtin_inff();
+        skip = diff > threshold ? __float_as_uint(sk.x) : RVB_BVH_EMPTY;
         float4 chunk = vol;
         if (c == 2) chunk = make_float4(p.x, p.y, p.z, diff);
-        else if (c == 3) chunk = make_float4(new_dist, __uint_as_float(surface), __uint_as_float(h.tri), __uint_as_float(pair_tag));   // tag: pair + 1, non-zero = valid
-        const uint64_t record = (uint64_t) ray * a.nreflections + index;
+        else if (c == 3) chunk = make_float4(new_dist, threshold, __uint_as_float(h.tri), __uint_as_float(pair_tag));   // tag: pair + 1, non-zero = valid
+        // (the product is formed here, one v_mad_u64_u32 per bounce: hoisted out of the loop it would hold two more VGPRs for
+        // the whole traversal, which at the 64-register budget of 8 waves per SIMD means a spill)
+        uint32_t ray_here = ray;
+        asm volatile("" : "+v"(ray_here));
+        const uint64_t record = (uint64_t) ray_here * a.nreflections + index;
         store_stream(reinterpret_cast<float4 *>(a.impulses + record) + c, chunk);
         if (c == 0 && index < RVB_NUM_IMAGE_SOURCE - 1)
             a.early[ray * (RVB_NUM_IMAGE_SOURCE - 1) + index] = h.tri;
@@ -649,8 +667,9 @@ __global__ __launch_bounds__(WAVE, 8) void path_kernel(TraceArgs a)
         source = mk3(s4.x, s4.y, s4.z);
     }
     const float4 d4 = a.directions[local];
+    const float len2 = d4.x * d4.x + d4.y * d4.y + d4.z * d4.z;
     PathJob<SURF_LDS> job = {a, (uint32_t) ray, threadIdx.x & 3u, source, mk3(d4.x, d4.y, d4.z), 0.0f,
-                   make_float4(1.0f, 1.0f, 1.0f, 1.0f), 0u, true, surf_lds, pair + 1u};
+                   make_float4(1.0f, 1.0f, 1.0f, 1.0f), 0u, true, surf_lds, pair + 1u, RVB_BVH_EMPTY, fabsf(len2 - 1.0f) < 1e-3f};
 #if RVB_PATH_JOBS == 2
 #if RVB_LDS_NODES
     traverse_jobs_vote(a.scene, stack_lds + q, job, lds_nodes);
@@ -664,7 +683,7 @@ __global__ __launch_bounds__(WAVE, 8) void path_kernel(TraceArgs a)
     float tmax;
     while (job.next(o, d, tmax)) {
         Hit h;
-        const bool hit = traverse_quad<false>(a.scene, o, d, tmax, stack_lds + q, h);
+        const bool hit = traverse_quad<false>(a.scene, o, d, tmax, stack_lds + q, h, job.skip);
         job.done(hit, h);
     }
 #endif
@@ -858,7 +877,9 @@ struct ShadowJob {
     float tmin, tmax_seen;               // arrival-time range of the non-zero impulses this lane's quad produced
     uint32_t pair;                       // pair of the current record (several pairs per launch only)
     lds_float4_ptr surf_lds;             // surface table in LDS; unused when !SURF_LDS
+    uint32_t skip;                       // own-plane subtree of the triangle the shadow ray starts on, RVB_BVH_EMPTY = none
 
+    __device__ __forceinline__ uint32_t skip_ref() const { return skip; }
     __device__ __forceinline__ bool next(v3 & o_, v3 & d_, float & tmax)
     {
         while (g < total) {
@@ -877,7 +898,12 @@ struct ShadowJob {
                 pair = tag - 1u;
             }
             new_dist = quad_bcast_f<3>(mine.x);
-            surface = quad_bcast_u<3>(__float_as_uint(mine.y));
+            const float threshold = quad_bcast_f<3>(mine.y);
+            // the triangle's shading record (the quad's lanes read the same 32 bytes): surface, and the own-plane skip
+            const float4 * shade = reinterpret_cast<const float4 *>(a.scene.shade + quad_bcast_u<3>(__float_as_uint(mine.z)));
+            const float4 sh = shade[0];
+            const uint32_t skip_ref = __float_as_uint(shade[1].x);
+            surface = __float_as_uint(sh.w);
             p = mk3(quad_bcast_f<2>(mine.x), quad_bcast_f<2>(mine.y), quad_bcast_f<2>(mine.z));
             diff = quad_bcast_f<2>(mine.w);
             const v3 b2p = mic - p;               // kernel.cpp:282-286
@@ -885,6 +911,7 @@ struct ShadowJob {
             o_ = p;
             d_ = normalize3(b2p);
             tmax = mag;
+            skip = fabsf(dot3(mk3(sh.x, sh.y, sh.z), d_)) > threshold ? skip_ref : RVB_BVH_EMPTY;
             return true;
         }
         return false;
@@ -960,6 +987,7 @@ __global__ __launch_bounds__(WAVE, RVB_SHADOW_WAVES) void shadow_kernel(TraceArg
     job.tmin = __builtin_inff();
     job.tmax_seen = 0.0f;
     job.surf_lds = stage_surfaces(a, stack_lds + a.stack_entries * QUADS_PER_BLOCK);
+    job.skip = RVB_BVH_EMPTY;
 #if RVB_SHADOW_JOBS
     traverse_jobs<true>(a.scene, stack_lds + q, job);
 #else
@@ -968,7 +996,7 @@ __global__ __launch_bounds__(WAVE, RVB_SHADOW_WAVES) void shadow_kernel(TraceArg
     float tmax;
     while (job.next(o, d, tmax)) {
         Hit h;
-        const bool blocked = traverse_quad<true>(a.scene, o, d, tmax, stack_lds + q, h);
+        const bool blocked = traverse_quad<true>(a.scene, o, d, tmax, stack_lds + q, h, job.skip);
         job.done(blocked, h);
     }
 #endif

@@ -211,12 +211,11 @@ int main(int argc, char ** argv)
         size_t by_lvl[16] = {0}, none = 0, ngroups = 0;
         std::vector<uint32_t> parent_level_of_ref;
         for (const BvhTri & t : base.bs.tris) {
-            const TriSkip & sk = base.bs.skip[t.index];
+            const TriShade & sk = base.bs.shade[t.index];
             if (sk.group != 0xFFFFFFFFu && sk.group + 1 > ngroups) ngroups = sk.group + 1;
-            if (sk.ref == RVB_BVH_EMPTY) { ++none; continue; }
-            // find the level: search the node that has this child ref (refs are unique)
+            if (sk.skip_ref == RVB_BVH_EMPTY) { ++none; continue; }
             int lvl = 15;
-            if (!(sk.ref & RVB_BVH_LEAF)) lvl = base.level[sk.ref >> RVB_BVH_NODE_SHIFT] - 1;
+            if (!(sk.skip_ref & RVB_BVH_LEAF)) lvl = base.level[sk.skip_ref >> RVB_BVH_NODE_SHIFT] - 1;
             else lvl = 14;                                // leaf-level skip
             ++by_lvl[lvl < 0 ? 0 : lvl];
         }
@@ -240,7 +239,7 @@ int main(int argc, char ** argv)
         }
         dirs = gdirs.data();
     }
-    unsigned long long verified = 0, mismatches = 0;
+    unsigned long long verified = 0, mismatches = 0, verified_any = 0, mismatches_any = 0;
 
     const double C_NODE = 56, C_LEAF = 125, C_DONE = 115;   // incl. ~6 for the vote        // wave instructions per step (from the ISA)
     for (int p = 0; p < (verify ? 1 : 14); ++p) {
@@ -341,16 +340,16 @@ int main(int argc, char ** argv)
                         const TriShade & sh = s.bs.shade[q[i].best_i];
                         v3 n = mk3(sh.n[0], sh.n[1], sh.n[2]);
                         v3 pnt = r[i].o + r[i].d * q[i].best_t;
-                        const TriSkip & sk = s.bs.skip[q[i].best_i];
-                        const float thr = fmaf(sk.b, q[i].best_t, sk.a), cosine = fabsf(dot3(n, r[i].d));
-                        const bool use_skip = getenv("TRAVSIM_SKIP") != nullptr;
+                        // the product's rule (PathJob::done, trace_kernels.hip): threshold from the segment that ended here
+                        const float thr = fmaf(sh.skip_b, q[i].best_t, sh.skip_a), cosine = fabsf(dot3(n, r[i].d));
+                        const bool use_skip = !(getenv("TRAVSIM_SKIP") && getenv("TRAVSIM_SKIP")[0] == '0');
                         if (hitpts.size() < 400000) { hitpts.push_back(pnt); hittri.push_back(q[i].best_i); hitthr.push_back(thr); }
                         r[i].d = reflect3(n, r[i].d);
                         r[i].o = pnt;
                         if (++r[i].bounce >= nrefl) { st[i] = IDLE; continue; }
                         s.begin(q[i], r[i].o, r[i].d, false, 0.0f);
                         ++skips_possible;
-                        if (use_skip && sk.ref != RVB_BVH_EMPTY && cosine > thr) { q[i].skip = sk.ref; ++skips_set; }
+                        if (use_skip && cosine > thr) { q[i].skip = sh.skip_ref; skips_set += sh.skip_ref != RVB_BVH_EMPTY; }
                         st[i] = NODE;
                     }
                 }
@@ -391,10 +390,9 @@ int main(int argc, char ** argv)
                         sh.begin(q[i], pnt, normalize3(b2p), true, length3(b2p));
                         {
                             const uint32_t rec = order[w0 + (nextj[i] - 1) * 16 + i];
-                            const TriSkip & sk = base.bs.skip[hittri[rec]];
                             const TriShade & shd = base.bs.shade[hittri[rec]];
-                            const float cosine = fabsf(dot3(mk3(shd.n[0], shd.n[1], shd.n[2]), q[i].d));
-                            if (getenv("TRAVSIM_SKIP") && sk.ref != RVB_BVH_EMPTY && cosine > hitthr[rec]) q[i].skip = sk.ref;
+                            const float cosine = fabsf(dot3(mk3(shd.n[0], shd.n[1], shd.n[2]), q[i].d));       // ShadowJob::next
+                            if (!(getenv("TRAVSIM_SKIP") && getenv("TRAVSIM_SKIP")[0] == '0') && cosine > hitthr[rec]) q[i].skip = shd.skip_ref;
                         }
                         st[i] = NODE;
                     };
@@ -423,7 +421,23 @@ int main(int argc, char ** argv)
                         }
                         if (act == NODE) { ++w_node; an += cn; for (int i = 0; i < 16; ++i) if (st[i] == NODE) { sh.node_step(q[i]); classify(i); } }
                         else if (act == LEAF) { ++w_leaf; al += cl; for (int i = 0; i < 16; ++i) if (st[i] == LEAF) { bool f = sh.leaf_step(q[i]); if (f) st[i] = DONE; else classify(i); } }
-                        else { ++w_done; ad += cd; for (int i = 0; i < 16; ++i) if (st[i] == DONE) start(i); }
+                        else {
+                            ++w_done; ad += cd;
+                            for (int i = 0; i < 16; ++i) if (st[i] == DONE) {
+                                if (verify && mode == 0 && p == 0) {            // any-hit against brute force (kernel.cpp:295)
+                                    bool blocked = false;
+                                    for (const BvhTri & t : sh.bs.tris) {
+                                        float dist = mt_intersect(mk3(t.v0[0], t.v0[1], t.v0[2]), mk3(t.e0[0], t.e0[1], t.e0[2]), mk3(t.e1[0], t.e1[1], t.e1[2]), q[i].o, q[i].d);
+                                        if (dist > RVB_EPSILON && dist <= q[i].tmax) { blocked = true; break; }
+                                    }
+                                    ++verified_any;
+                                    if (blocked != q[i].found && ++mismatches_any <= 10)
+                                        printf("SHADOW MISMATCH bvh %d brute %d o=(%.9g %.9g %.9g) d=(%.9g %.9g %.9g) tmax %.9g\n", (int) q[i].found, (int) blocked,
+                                               q[i].o.x, q[i].o.y, q[i].o.z, q[i].d.x, q[i].d.y, q[i].d.z, q[i].tmax);
+                                }
+                                start(i);
+                            }
+                        }
                     }
                 }
                 const double nrec = (double) (order.size() / per_wave * per_wave);
@@ -434,6 +448,7 @@ int main(int argc, char ** argv)
             }
         }
     }
-    if (verify) printf("verify: %llu closest-hit queries against brute force, %llu mismatches\n", verified, mismatches);
+    if (verify) printf("verify: %llu closest-hit queries against brute force, %llu mismatches; %llu any-hit (shadow) queries, %llu mismatches\n",
+                       verified, mismatches, verified_any, mismatches_any);
     return 0;
 }
