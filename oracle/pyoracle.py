@@ -18,6 +18,7 @@ from parallel_reverb_raytracer_amd.dtypes import (ATTENUATED, IMPULSE, NUM_IMAGE
                                                   aligned_copy, aligned_zeros)
 
 ORACLE_SO = os.path.join(_HERE, "_build", "librvb_oracle.so")
+ORACLE_GPU_SO = os.path.join(_HERE, "_build", "librvb_oracle_gpu.so")
 REF_SO = os.path.join(_HERE, "_ref", "librvb_ref.so")
 
 _c_f = ctypes.POINTER(ctypes.c_float)
@@ -70,8 +71,13 @@ class Oracle:
             self.lib.rvbo_flatten_bins.restype = _u64
             self.lib.rvbo_collect_images.restype = _u64
             self.lib.rvbo_hrtf_index.restype = ctypes.c_int64
+        elif kind == "gpu":
+            # the kernel part of rvb_oracle.c compiled for the GPU, one thread per ray (oracle/gpu_oracle.hip): raytrace only
+            self.lib = ctypes.CDLL(ORACLE_GPU_SO)
         elif kind == "reference":
             self.lib = ctypes.CDLL(REF_SO)
+        elif kind == "reference_alt":            # oracle/sensitivity.py: the other conforming built-ins (build_ref.sh alt)
+            self.lib = ctypes.CDLL(os.path.join(_HERE, "_ref", "librvb_ref_alt.so"))
         else:
             raise ValueError(kind)
 
@@ -89,6 +95,12 @@ class Oracle:
                 _ptr(impulses), _ptr(image), _ptr(index)]
         if self.kind == "port":
             self.lib.rvbo_raytrace(*args, ctypes.c_int(nthreads if nthreads > 0 else cpu_threads()))
+        elif self.kind == "gpu":
+            rc = self.lib.rvbo_gpu_raytrace(_ptr(directions), _u64(nrays), _ptr(triangles), _u64(triangles.shape[0]), _ptr(vertices),
+                                            _u64(vertices.shape[0]), _ptr(surfaces), _u64(surfaces.shape[0]), _f3(mic), _f3(source),
+                                            _u64(nreflections), _f8(air), _ptr(impulses), _ptr(image), _ptr(index), ctypes.c_int(0))
+            if rc:
+                raise RuntimeError("rvbo_gpu_raytrace failed")
         else:
             self.lib.rvb_ref_raytrace(*args)
         return impulses, image, index
@@ -97,7 +109,7 @@ class Oracle:
     def attenuate_speaker(self, mic, impulses, direction, coefficient):
         impulses = aligned_copy(impulses)
         out = aligned_zeros(impulses.shape[0], ATTENUATED)
-        fn = self.lib.rvbo_attenuate_speaker if self.kind == "port" else self.lib.rvb_ref_attenuate
+        fn = self.lib.rvbo_attenuate_speaker if self.kind in ("port", "gpu") else self.lib.rvb_ref_attenuate
         fn(_f3(mic), _ptr(impulses), _u64(impulses.shape[0]), _f3(direction), ctypes.c_float(coefficient), _ptr(out))
         return out
 

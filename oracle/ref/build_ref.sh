@@ -37,12 +37,17 @@ with open(sys.argv[2], 'w') as f:
     f.write(src[begin:end])
 PY
 
+# `build_ref.sh alt`: a second library, librvb_ref_alt.so, with the alternative conforming built-ins of ref_builtins.cl and the
+# kernel text contracted into fused multiply-adds (FP_CONTRACT ON, the OpenCL default) — input of oracle/sensitivity.py only.
+VARIANT="${1:-}"
+CONTRACT=off; EXTRA=(); NAME=librvb_ref.so
+if [ "$VARIANT" = "alt" ]; then CONTRACT=fast; EXTRA=(-DRVB_REF_ALT_BUILTINS -mfma); NAME=librvb_ref_alt.so; fi
 CLFLAGS=(-x cl -cl-std=CL1.2 -Xclang -finclude-default-header
-         -target x86_64-unknown-linux-gnu -mavx2 -ffp-contract=off -O1 -w -fPIC -I "$TMP")
+         -target x86_64-unknown-linux-gnu -mavx2 -ffp-contract=$CONTRACT -O1 -w -fPIC -I "$TMP" "${EXTRA[@]}")
 
 "$CLANG" "${CLFLAGS[@]}" -c "$HERE/ref_wrap.cl" -o "$TMP/ref_wrap.o"
 "$CLANG" "${CLFLAGS[@]}" -c "$HERE/ref_builtins.cl" -o "$TMP/ref_builtins.o"
 gcc -O2 -fPIC -fopenmp -ffp-contract=off -c "$HERE/ref_harness.c" -o "$TMP/ref_harness.o"
-gcc -shared -fopenmp -o "$OUT/librvb_ref.so" "$TMP/ref_harness.o" "$TMP/ref_wrap.o" "$TMP/ref_builtins.o" -lm
+gcc -shared -fopenmp -o "$OUT/$NAME" "$TMP/ref_harness.o" "$TMP/ref_wrap.o" "$TMP/ref_builtins.o" -lm
 
-echo "build_ref: wrote $OUT/librvb_ref.so"
+echo "build_ref: wrote $OUT/$NAME"

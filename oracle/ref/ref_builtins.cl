@@ -25,6 +25,52 @@ double rvb_ref_pow_d(double, double);      // libm, supplied by ref_harness.c
 double rvb_ref_atan2_d(double, double);    // libm, supplied by ref_harness.c
 float  rvb_ref_sqrtf(float);               // libm sqrtf (IEEE correctly rounded)
 
+#ifdef RVB_REF_ALT_BUILTINS
+// ---- a SECOND conforming choice (oracle/sensitivity.py): what a GPU OpenCL compiler typically emits -------------------
+// dot / cross as fused multiply-adds (OpenCL C's FP_CONTRACT is ON by default), normalize as a multiply by the reciprocal
+// square root, pow / atan2 in binary32 (libm powf / atan2f: within 1 ulp, not correctly rounded).  The kernel text itself is
+// then compiled with -ffp-contract=fast as well (build_ref.sh alt).  Nothing here is used to define parity: it measures how
+// many discrete outcomes move when the implementation-defined parts of OpenCL move.
+float rvb_ref_powf(float, float);
+float rvb_ref_atan2f(float, float);
+
+float __attribute__((overloadable)) dot(float3 a, float3 b)
+{
+    return __builtin_fmaf(a.x, b.x, __builtin_fmaf(a.y, b.y, a.z * b.z));
+}
+
+float3 __attribute__((overloadable)) cross(float3 a, float3 b)
+{
+    return (float3)(__builtin_fmaf(a.y, b.z, -(a.z * b.y)),
+                    __builtin_fmaf(a.z, b.x, -(a.x * b.z)),
+                    __builtin_fmaf(a.x, b.y, -(a.y * b.x)));
+}
+
+float __attribute__((overloadable)) length(float3 v)
+{
+    return rvb_ref_sqrtf(__builtin_fmaf(v.x, v.x, __builtin_fmaf(v.y, v.y, v.z * v.z)));
+}
+
+float __attribute__((overloadable)) length(float2 v)
+{
+    return rvb_ref_sqrtf(__builtin_fmaf(v.x, v.x, v.y * v.y));
+}
+
+float __attribute__((overloadable)) distance(float3 a, float3 b)
+{
+    float3 d = a - b;
+    return rvb_ref_sqrtf(__builtin_fmaf(d.x, d.x, __builtin_fmaf(d.y, d.y, d.z * d.z)));
+}
+
+float3 __attribute__((overloadable)) normalize(float3 v)
+{
+    float l2 = __builtin_fmaf(v.x, v.x, __builtin_fmaf(v.y, v.y, v.z * v.z));
+    if (l2 == 0.0f)
+        return v;
+    float r = 1.0f / rvb_ref_sqrtf(l2);        // rsqrt, then three multiplies
+    return (float3)(v.x * r, v.y * r, v.z * r);
+}
+#else
 float __attribute__((overloadable)) dot(float3 a, float3 b)
 {
     return a.x * b.x + a.y * b.y + a.z * b.z;
@@ -61,6 +107,8 @@ float3 __attribute__((overloadable)) normalize(float3 v)
     return (float3)(v.x / l, v.y / l, v.z / l);
 }
 
+#endif
+
 int __attribute__((overloadable)) all(int3 v)
 {
     return (v.x < 0) && (v.y < 0) && (v.z < 0);
@@ -72,6 +120,15 @@ int __attribute__((overloadable)) any(int8 v)
         || (v.s4 < 0) || (v.s5 < 0) || (v.s6 < 0) || (v.s7 < 0);
 }
 
+#ifdef RVB_REF_ALT_BUILTINS
+float8 __attribute__((overloadable)) pow(float8 x, float8 y)
+{
+    float8 r;
+    r.s0 = rvb_ref_powf(x.s0, y.s0); r.s1 = rvb_ref_powf(x.s1, y.s1); r.s2 = rvb_ref_powf(x.s2, y.s2); r.s3 = rvb_ref_powf(x.s3, y.s3);
+    r.s4 = rvb_ref_powf(x.s4, y.s4); r.s5 = rvb_ref_powf(x.s5, y.s5); r.s6 = rvb_ref_powf(x.s6, y.s6); r.s7 = rvb_ref_powf(x.s7, y.s7);
+    return r;
+}
+#else
 float8 __attribute__((overloadable)) pow(float8 x, float8 y)
 {
     float8 r;
@@ -86,15 +143,25 @@ float8 __attribute__((overloadable)) pow(float8 x, float8 y)
     return r;
 }
 
+#endif
+
 float __attribute__((overloadable)) fabs(float x)
 {
     return as_float(as_uint(x) & 0x7fffffffu);
 }
 
+#ifdef RVB_REF_ALT_BUILTINS
+float __attribute__((overloadable)) atan2(float y, float x)
+{
+    return rvb_ref_atan2f(y, x);
+}
+#else
 float __attribute__((overloadable)) atan2(float y, float x)
 {
     return (float) rvb_ref_atan2_d((double) y, (double) x);
 }
+
+#endif
 
 float __attribute__((overloadable)) degrees(float x)
 {

@@ -68,6 +68,8 @@ size_t _Z13get_global_idj(unsigned dim) { (void) dim; return g_global_id; }
 double rvb_ref_pow_d(double x, double y) { return pow(x, y); }
 double rvb_ref_atan2_d(double y, double x) { return atan2(y, x); }
 float rvb_ref_sqrtf(float x) { return sqrtf(x); }
+float rvb_ref_powf(float x, float y) { return powf(x, y); }          /* the alternative built-ins only (oracle/sensitivity.py) */
+float rvb_ref_atan2f(float y, float x) { return atan2f(y, x); }
 
 /* --- NDRange loops ------------------------------------------------------- */
 void rvb_ref_raytrace

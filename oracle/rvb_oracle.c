@@ -8,6 +8,12 @@
  */
 #include "rvb_oracle.h"
 
+/* The part of this file up to raytrace_one is also compiled for the GPU by oracle/gpu_oracle.hip (same source, one thread per
+ * ray: a brute-force check of whole full-size runs): RVBO_FN marks those functions, RVBO_KERNEL_PART_ONLY drops the rest. */
+#ifndef RVBO_FN
+#define RVBO_FN
+#endif
+
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -21,29 +27,29 @@ typedef struct { v3 position, direction; } ray_t; /* reference kernel.cpp:17-20 
 typedef struct { uint64_t primitive; float distance; int intersects; } hit_t; /* kernel.cpp:34-38 */
 
 /* ---- OpenCL built-ins, as defined in oracle/ref/ref_builtins.cl ---------- */
-static inline v3 v3_make(float x, float y, float z) { v3 r = {x, y, z}; return r; }
-static inline v3 v3_add(v3 a, v3 b) { return v3_make(a.x + b.x, a.y + b.y, a.z + b.z); }
-static inline v3 v3_sub(v3 a, v3 b) { return v3_make(a.x - b.x, a.y - b.y, a.z - b.z); }
-static inline v3 v3_scale(v3 a, float s) { return v3_make(a.x * s, a.y * s, a.z * s); }
-static inline v3 v3_neg(v3 a) { return v3_make(-a.x, -a.y, -a.z); }
-static inline float v3_dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-static inline v3 v3_cross(v3 a, v3 b)
+static inline RVBO_FN v3 v3_make(float x, float y, float z) { v3 r = {x, y, z}; return r; }
+static inline RVBO_FN v3 v3_add(v3 a, v3 b) { return v3_make(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline RVBO_FN v3 v3_sub(v3 a, v3 b) { return v3_make(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline RVBO_FN v3 v3_scale(v3 a, float s) { return v3_make(a.x * s, a.y * s, a.z * s); }
+static inline RVBO_FN v3 v3_neg(v3 a) { return v3_make(-a.x, -a.y, -a.z); }
+static inline RVBO_FN float v3_dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline RVBO_FN v3 v3_cross(v3 a, v3 b)
 {
     return v3_make(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
-static inline float v3_length(v3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
-static inline v3 v3_normalize(v3 a)
+static inline RVBO_FN float v3_length(v3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+static inline RVBO_FN v3 v3_normalize(v3 a)
 {
     float l = v3_length(a);
     if (l == 0.0f)
         return a;
     return v3_make(a.x / l, a.y / l, a.z / l);
 }
-static inline float pow_cr(float x, float y) { return (float) pow((double) x, (double) y); }
-static inline float atan2_cr(float y, float x) { return (float) atan2((double) y, (double) x); }
-static inline float degrees_f(float x) { return x * 57.295779513082320877f; }
+static inline RVBO_FN float pow_cr(float x, float y) { return (float) pow((double) x, (double) y); }
+static inline RVBO_FN float atan2_cr(float y, float x) { return (float) atan2((double) y, (double) x); }
+static inline RVBO_FN float degrees_f(float x) { return x * 57.295779513082320877f; }
 
-static inline v3 load_vertex(const float * vertices, uint64_t i)
+static inline RVBO_FN v3 load_vertex(const float * vertices, uint64_t i)
 {
     return v3_make(vertices[4 * i + 0], vertices[4 * i + 1], vertices[4 * i + 2]);
 }
@@ -54,7 +60,7 @@ static const float SECONDS_PER_METER = (float) (1.0 / 340.000000);
 /* ---- geometry ------------------------------------------------------------ */
 
 /* reference kernel.cpp:62-88 */
-static float triangle_vert_intersection(const triverts * v, const ray_t * ray)
+static RVBO_FN float triangle_vert_intersection(const triverts * v, const ray_t * ray)
 {
     v3 e0 = v3_sub(v->v1, v->v0);
     v3 e1 = v3_sub(v->v2, v->v0);
@@ -82,7 +88,7 @@ static float triangle_vert_intersection(const triverts * v, const ray_t * ray)
 }
 
 /* reference kernel.cpp:95-107, :121-125 */
-static triverts gather_verts(const RvboTriangle * t, const float * vertices)
+static RVBO_FN triverts gather_verts(const RvboTriangle * t, const float * vertices)
 {
     triverts v;
     v.v0 = load_vertex(vertices, t->v0);
@@ -92,7 +98,7 @@ static triverts gather_verts(const RvboTriangle * t, const float * vertices)
 }
 
 /* reference kernel.cpp:109-116 */
-static v3 triangle_verts_normal(const triverts * t)
+static RVBO_FN v3 triangle_verts_normal(const triverts * t)
 {
     v3 e0 = v3_sub(t->v1, t->v0);
     v3 e1 = v3_sub(t->v2, t->v0);
@@ -100,7 +106,7 @@ static v3 triangle_verts_normal(const triverts * t)
 }
 
 /* reference kernel.cpp:129-133: direction - (normal * 2 * dot(direction, normal)) */
-static v3 reflect(v3 normal, v3 direction)
+static RVBO_FN v3 reflect(v3 normal, v3 direction)
 {
     v3 n2 = v3_scale(normal, 2.0f);
     float d = v3_dot(direction, normal);
@@ -108,7 +114,7 @@ static v3 reflect(v3 normal, v3 direction)
 }
 
 /* reference kernel.cpp:167-192 */
-static hit_t ray_triangle_intersection
+static RVBO_FN hit_t ray_triangle_intersection
 (   const ray_t * ray, const RvboTriangle * triangles, uint64_t numtriangles, const float * vertices)
 {
     hit_t ret = {0, 0.0f, 0};
@@ -127,7 +133,7 @@ static hit_t ray_triangle_intersection
 }
 
 /* reference kernel.cpp:194-214: pow(M_E, distance * AIR) * 1 */
-static void attenuation_for_distance(float distance, const float air[8], float out[8])
+static RVBO_FN void attenuation_for_distance(float distance, const float air[8], float out[8])
 {
     const float e = (float) 2.7182818284590452354; /* M_E converted to the float8 element type */
     for (int b = 0; b != 8; ++b)
@@ -135,7 +141,7 @@ static void attenuation_for_distance(float distance, const float air[8], float o
 }
 
 /* reference kernel.cpp:216-221: *p += -n * dot(n, *p - t->v0) * 2 */
-static void mirror_point(v3 * p, const triverts * t)
+static RVBO_FN void mirror_point(v3 * p, const triverts * t)
 {
     v3 n = triangle_verts_normal(t);
     float d = v3_dot(n, v3_sub(*p, t->v0));
@@ -144,7 +150,7 @@ static void mirror_point(v3 * p, const triverts * t)
 }
 
 /* reference kernel.cpp:223-229 */
-static void mirror_verts(triverts * in, const triverts * t)
+static RVBO_FN void mirror_verts(triverts * in, const triverts * t)
 {
     mirror_point(&in->v0, t);
     mirror_point(&in->v1, t);
@@ -152,7 +158,7 @@ static void mirror_verts(triverts * in, const triverts * t)
 }
 
 /* reference kernel.cpp:243-265 */
-static void add_image
+static RVBO_FN void add_image
 (   v3 mic_position, v3 mic_reflection, v3 source,
     RvboImpulse * image_source, uint64_t * image_source_index,
     uint64_t thread_index, uint64_t thread_offset_index,
@@ -177,7 +183,7 @@ static void add_image
 }
 
 /* reference kernel.cpp:274-296 */
-static int point_intersection
+static RVBO_FN int point_intersection
 (   v3 begin, v3 point, const RvboTriangle * triangles, uint64_t numtriangles, const float * vertices)
 {
     v3 begin_to_point = v3_sub(point, begin);
@@ -188,10 +194,10 @@ static int point_intersection
 }
 
 /* reference kernel.cpp:298-302 */
-static v3 get_direction(v3 from, v3 to) { return v3_normalize(v3_sub(to, from)); }
+static RVBO_FN v3 get_direction(v3 from, v3 to) { return v3_normalize(v3_sub(to, from)); }
 
 /* reference kernel.cpp:304-503, one work-item */
-static void raytrace_one
+static RVBO_FN void raytrace_one
 (   uint64_t i, const float * directions, v3 position,
     const RvboTriangle * triangles, uint64_t numtriangles, const float * vertices,
     v3 source, const RvboSurface * surfaces,
@@ -310,6 +316,7 @@ static void raytrace_one
     }
 }
 
+#ifndef RVBO_KERNEL_PART_ONLY
 void rvbo_raytrace
 (   const float * directions, uint64_t nrays,
     const RvboTriangle * triangles, uint64_t ntriangles,
@@ -601,3 +608,5 @@ void rvbo_flatten(const RvboAttenuated * impulses, uint64_t n, float samplerate,
             out[(uint64_t) b * nbins + sample] += impulses[i].volume[b];
     }
 }
+
+#endif /* RVBO_KERNEL_PART_ONLY */

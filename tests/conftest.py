@@ -32,6 +32,20 @@ def oracle():
 
 
 @pytest.fixture(scope="session")
+def gpu_oracle():
+    """The same oracle source compiled for the GPU, one thread per ray, brute force (oracle/gpu_oracle.hip): checks whole
+    full-size runs.  Test infrastructure only; needs a GPU."""
+    so = os.path.join(ROOT, "oracle", "_build", "librvb_oracle_gpu.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "_build/librvb_oracle_gpu.so"])
+    # load order: torch's HIP runtime, then the product library, then this one (two HIP runtimes live in the process, see capi.py)
+    from parallel_reverb_raytracer_amd import capi
+    capi.load_library()
+    import pyoracle
+    return pyoracle.Oracle("gpu")
+
+
+@pytest.fixture(scope="session")
 def reference_oracle():
     """The reference's own kernels compiled for the host (oracle/_ref); skipped where not built."""
     import pyoracle

@@ -147,6 +147,57 @@ def test_c4_atrium_262k_triangles_256_bounces_small_ray_set(ctx, oracle):
     assert _same(got[sample].reshape(-1), want)
 
 
+def _ulp_distance(a, b):
+    ia, ib = a.view(np.int32).astype(np.int64), b.view(np.int32).astype(np.int64)
+    ia = np.where(ia < 0, np.int64(-2147483648) - ia, ia)
+    ib = np.where(ib < 0, np.int64(-2147483648) - ib, ib)
+    return np.abs(ia - ib)
+
+
+def check_every_ray_against_gpu_brute_force(ctx, oracle, gpu_oracle, scene, mic, src, dirs, nrefl, cross_check_rays=48):
+    """The product's trace of ALL rays against the oracle source run brute force on the GPU (one thread per ray, every triangle
+    tested for every query).  The GPU build of the oracle is first held against its CPU build on a few rays; then every impulse of
+    every ray is compared: position and time bit for bit, volumes within one ulp (the device's binary64 pow and glibc's may round
+    a handful of values differently), image-source slots exactly.  Returns a small report."""
+    nrays = dirs.shape[0]
+    sample = np.sort(np.random.default_rng(3).choice(nrays, cross_check_rays, replace=False))
+    cpu, cpu_image, cpu_index = oracle.raytrace(scene, mic, src, dirs[sample], nrefl, AIR_COEFFICIENTS)
+    gpu, gpu_image, gpu_index = gpu_oracle.raytrace(scene, mic, src, dirs[sample], nrefl, AIR_COEFFICIENTS)
+    assert np.array_equal(cpu["position"], gpu["position"]) and np.array_equal(cpu["time"], gpu["time"])
+    assert np.array_equal(cpu_index, gpu_index) and np.array_equal(cpu_image["position"], gpu_image["position"])
+    assert _ulp_distance(cpu["volume"], gpu["volume"]).max() <= 1
+
+    ctx.set_scene(scene)
+    ctx.raytrace(mic, src, dirs, nrefl, AIR_COEFFICIENTS)
+    got = ctx.get_raw_diffuse()
+    cands = ctx.get_image_candidates()
+    want, image, index = gpu_oracle.raytrace(scene, mic, src, dirs, nrefl, AIR_COEFFICIENTS)
+    assert np.array_equal(got["position"][:, :3], want["position"][:, :3]), "a hit point differs from brute force"
+    assert np.array_equal(got["time"], want["time"]), "an arrival time differs from brute force"
+    ulps = _ulp_distance(got["volume"], want["volume"])
+    assert ulps.max() <= 1
+    # image sources: every valid slot of every ray
+    idx = index.reshape(nrays, 10)
+    rays, slots = np.nonzero(idx[:, 1:])
+    order = np.lexsort((slots, rays))
+    assert cands.shape[0] == rays.shape[0]
+    assert np.array_equal(cands["ray"], rays[order].astype(np.uint64)) and np.array_equal(cands["slot"], (slots[order] + 1).astype(np.uint32))
+    assert np.array_equal(cands["index"], idx[rays[order], slots[order] + 1].astype(np.uint32))
+    img = image.reshape(nrays, 10)[rays[order], slots[order] + 1]
+    assert np.array_equal(cands["impulse"]["position"][:, :3], img["position"][:, :3]) and np.array_equal(cands["impulse"]["time"], img["time"])
+    return {"rays": int(nrays), "impulses": int(got.shape[0]), "volume_values_off_by_one_ulp": int((ulps == 1).sum()),
+            "image_source_slots": int(rays.shape[0])}
+
+
+def test_c2_every_ray_of_the_full_run_against_brute_force_on_the_gpu(ctx, oracle, gpu_oracle):
+    """BASELINE config C2, ALL 100 000 rays x 128 bounces: 12.8 M closest-hit queries, 12.8 M shadow rays and every image-source
+    validation against a brute-force scan of all 75 252 triangles (about 2 x 10^12 triangle tests, on the GPU)."""
+    scene, info = scenes.cathedral(75000)
+    report = check_every_ray_against_gpu_brute_force(ctx, oracle, gpu_oracle, scene, info["mic"], info["source"],
+                                                     scenes.sphere_directions(100000, seed=1), 128)
+    print("C2 exhaustive:", report)
+
+
 def test_c3_per_gpu_share_125k_rays_at_a_ray_offset(ctx, oracle):
     """BASELINE config C3 = 1M rays x 128 over 8 GPUs: what ONE of the eight ranks runs — its contiguous 125 000-ray shard of
     the global seeded set (here rank 5's: ray_offset 625 000), traced as one resident round of waves (125 000 rays = 7 813
