@@ -198,6 +198,15 @@ def test_c2_every_ray_of_the_full_run_against_brute_force_on_the_gpu(ctx, oracle
     print("C2 exhaustive:", report)
 
 
+def test_c4_six_thousand_rays_x_256_bounces_every_ray_against_brute_force_on_the_gpu(ctx, oracle, gpu_oracle):
+    """BASELINE config C4's scene and depth (263 k triangles, 256 bounces): every impulse of 6 144 rays against brute force on
+    the GPU (0.8 x 10^12 triangle tests) — the divergence-stress scene, whose long chains amplify any wrong decision."""
+    scene, info = scenes.atrium(262000)
+    report = check_every_ray_against_gpu_brute_force(ctx, oracle, gpu_oracle, scene, info["mic"], info["source"],
+                                                     scenes.sphere_directions(6144, seed=4), 256, cross_check_rays=12)
+    print("C4 exhaustive:", report)
+
+
 def test_c3_per_gpu_share_125k_rays_at_a_ray_offset(ctx, oracle):
     """BASELINE config C3 = 1M rays x 128 over 8 GPUs: what ONE of the eight ranks runs — its contiguous 125 000-ray shard of
     the global seeded set (here rank 5's: ray_offset 625 000), traced as one resident round of waves (125 000 rays = 7 813
