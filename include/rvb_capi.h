@@ -82,6 +82,9 @@ int rvb_set_scene(rvb_ctx * ctx,
 int rvb_scene_info(rvb_ctx * ctx, uint64_t * nodes, uint64_t * kept_triangles, uint32_t * depth);
 
 /* ---- ray directions: replaces the per-group cl::copy of rayverb.cpp:593-598 ---------------- */
+/* Directions are unit vectors (reference getRandomDirections, helpers.cpp:63-81); RVB_ERR_INVALID for a direction that is not
+ * finite or whose length is outside [0.5, 2] (the range the pruning margins of the acceleration structure are derived for).
+ * The device variant borrows the caller's buffer and does not inspect it: the same contract is the caller's to keep. */
 int rvb_set_directions(rvb_ctx * ctx, const rvb_float3 * directions, uint64_t nrays);          /* host */
 int rvb_set_directions_device(rvb_ctx * ctx, const void * d_directions, uint64_t nrays);        /* device, borrowed */
 

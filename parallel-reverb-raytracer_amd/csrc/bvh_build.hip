@@ -500,12 +500,12 @@ std::string rvb_build_scene(const rvb_triangle * triangles, uint64_t ntriangles,
         for (float f : c9) finite = finite && std::isfinite(f);
         if (!finite)
             continue;   // NaN/inf vertices: every comparison of the triangle test fails -> never hit
-        // |det| <= |e0 x e1| for a unit direction; below EPSILON the triangle can never be hit
+        // |det| <= |d| |e0 x e1|; rvb_set_directions accepts |d| <= 2, so below EPSILON / 2 the triangle can never be hit
         // (quirk Q7).  Evaluated in double with a 1 % margin so nothing hittable is dropped.
         double e0[3] = {(double) p1.x - p0.x, (double) p1.y - p0.y, (double) p1.z - p0.z};
         double e1[3] = {(double) p2.x - p0.x, (double) p2.y - p0.y, (double) p2.z - p0.z};
         double cx = e0[1] * e1[2] - e0[2] * e1[1], cy = e0[2] * e1[0] - e0[0] * e1[2], cz = e0[0] * e1[1] - e0[1] * e1[0];
-        if (std::sqrt(cx * cx + cy * cy + cz * cz) * 1.01 < (double) RVB_EPSILON)
+        if (std::sqrt(cx * cx + cy * cy + cz * cz) * 2.02 < (double) RVB_EPSILON)
             continue;
 
         Prim p;

@@ -326,6 +326,17 @@ int rvb_set_directions(rvb_ctx * ctx, const rvb_float3 * directions, uint64_t nr
 {
     if (!ctx) return RVB_ERR_INVALID;
     if (nrays && !directions) return fail(ctx, RVB_ERR_INVALID, "rvb_set_directions: null directions");
+    // Unit vectors are the contract (reference getRandomDirections, helpers.cpp:63-81): distances, times and the diffuse cosine
+    // are only meaningful for |d| = 1.  The pruning margins of the acceleration structure (box padding, cull slack, the
+    // triangles dropped as unhittable at build time) hold for 0.5 <= |d| <= 2; anything outside, or not finite, is refused
+    // rather than traced with weaker guarantees.
+    for (uint64_t i = 0; i < nrays; ++i) {
+        const float * d = directions[i].s;
+        const float len2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+        if (!(len2 >= 0.25f && len2 <= 4.0f))
+            return fail(ctx, RVB_ERR_INVALID, "rvb_set_directions: direction " + std::to_string(i) + " is not a unit vector (length^2 = " +
+                                              std::to_string(len2) + "; 0.5 <= length <= 2 is accepted)");
+    }
     RVB_BIND(ctx);
     RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     RVB_HIP(ctx, ctx->directions_own.ensure(nrays * sizeof(rvb_float3)));

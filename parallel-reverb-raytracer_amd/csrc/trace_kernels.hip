@@ -319,6 +319,27 @@ __device__ __forceinline__ void traverse_jobs(const SceneDev & sc, uint32_t * __
 #undef RVB_RESET_QUERY
 }
 
+// min of two unsigned 64-bit keys.  The compiler's form is v_cmp_lt_u64 -> VCC and two v_cndmask_b32 that read VCC; the SECOND
+// select on one VCC value issues far slower than the first (tools/inst_probe.hip "cmpsel2_vcc": 3.0 ns against 0.9 ns for the
+// same select on an SGPR-pair mask at 8 waves per SIMD, and 5-10x that at low occupancy).  Here the mask lives in an SGPR pair.
+#ifndef RVB_MIN64_SGPR
+#define RVB_MIN64_SGPR 1
+#endif
+__device__ __forceinline__ unsigned long long min_u64(unsigned long long a, unsigned long long b)
+{
+#if RVB_MIN64_SGPR
+    unsigned long long mask;
+    uint32_t lo, hi;
+    // (s_nop 1: a VALU-written SGPR needs two wait states before a VALU reads it as a mask)
+    asm("v_cmp_lt_u64_e64 %0, %3, %4\n\ts_nop 1\n\tv_cndmask_b32_e64 %1, %6, %5, %0\n\tv_cndmask_b32_e64 %2, %8, %7, %0"
+        : "=&s"(mask), "=&v"(lo), "=&v"(hi)
+        : "v"(a), "v"(b), "v"((uint32_t) a), "v"((uint32_t) b), "v"((uint32_t) (a >> 32)), "v"((uint32_t) (b >> 32)));
+    return ((unsigned long long) hi << 32) | lo;
+#else
+    return a < b ? a : b;
+#endif
+}
+
 // Population count of a wave mask as a 32-bit scalar (the builtin's 64-bit result drags the comparisons that follow
 // onto the VALU as 64-bit compares).
 __device__ __forceinline__ int scalar_popcount(unsigned long long mask)
@@ -417,9 +438,9 @@ __device__ __forceinline__ void traverse_jobs_vote(const SceneDev & sc, uint32_t
                 // 64-bit compares.  "No hit" is (+inf, NONE), the largest key a lane can hold.
                 const bool valid = c < count && dist > RVB_EPSILON;
                 unsigned long long key = valid ? (((unsigned long long) __float_as_uint(dist) << 32) | idx) : NO_HIT_KEY;
-                key = min(key, dpp_u64<QP_SWAP1>(key));
-                key = min(key, dpp_u64<QP_SWAP2>(key));
-                best_key = min(best_key, key);
+                key = min_u64(key, dpp_u64<QP_SWAP1>(key));
+                key = min_u64(key, dpp_u64<QP_SWAP2>(key));
+                best_key = min_u64(best_key, key);
                 if (sp > 0) { --sp; ref = stack[sp * QUADS_PER_BLOCK]; } else ref = NONE;
             }
         } else {

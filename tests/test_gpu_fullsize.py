@@ -198,12 +198,12 @@ def test_c2_every_ray_of_the_full_run_against_brute_force_on_the_gpu(ctx, oracle
     print("C2 exhaustive:", report)
 
 
-def test_c4_six_thousand_rays_x_256_bounces_every_ray_against_brute_force_on_the_gpu(ctx, oracle, gpu_oracle):
-    """BASELINE config C4's scene and depth (263 k triangles, 256 bounces): every impulse of 6 144 rays against brute force on
-    the GPU (0.8 x 10^12 triangle tests) — the divergence-stress scene, whose long chains amplify any wrong decision."""
+def test_c4_sixteen_thousand_rays_x_256_bounces_every_ray_against_brute_force_on_the_gpu(ctx, oracle, gpu_oracle):
+    """BASELINE config C4's scene and depth (263 k triangles, 256 bounces): every impulse of 16 384 rays against brute force on
+    the GPU (2 x 10^12 triangle tests; one thread per ray, so the run time is that of ONE ray whatever the count) — the divergence-stress scene, whose long chains amplify any wrong decision."""
     scene, info = scenes.atrium(262000)
     report = check_every_ray_against_gpu_brute_force(ctx, oracle, gpu_oracle, scene, info["mic"], info["source"],
-                                                     scenes.sphere_directions(6144, seed=4), 256, cross_check_rays=12)
+                                                     scenes.sphere_directions(16384, seed=4), 256, cross_check_rays=12)
     print("C4 exhaustive:", report)
 
 

@@ -238,6 +238,28 @@ def test_edge_cases_empty_and_ragged(ctx, oracle):
     assert_impulses_equal(ctx.get_raw_images(False), oracle.collect_images(image, index, False))
 
 
+def test_directions_are_unit_vectors_by_contract(ctx, oracle):
+    """rvb_set_directions refuses what is not (nearly) a unit vector; lengths inside the accepted [0.5, 2] still trace to the
+    brute-force result (the own-plane skip stands down for them, the pruning margins are derived for that range)."""
+    from parallel_reverb_raytracer_amd import capi
+    scene, info = scenes.cathedral(3000)
+    ctx.set_scene(scene)
+    dirs = scenes.sphere_directions(640, seed=17).copy()
+    for bad in (np.float32(0.0), np.float32(3.0), np.float32(np.nan)):
+        broken = dirs.copy()
+        broken[5, :3] *= bad
+        with pytest.raises(capi.RvbError) as e:
+            ctx.set_directions(broken)
+        assert e.value.code == 1
+    scaled = dirs.copy()
+    scaled[::3, :3] *= np.float32(1.75)
+    scaled[1::3, :3] *= np.float32(0.6)
+    ctx.raytrace(info["mic"], info["source"], scaled, 24, AIR_COEFFICIENTS)
+    want, image, index = oracle.raytrace(scene, info["mic"], info["source"], scaled, 24, AIR_COEFFICIENTS)
+    assert_impulses_equal(ctx.get_raw_diffuse(), want)
+    assert_impulses_equal(ctx.get_raw_images(False), oracle.collect_images(image, index, False))
+
+
 def test_scene_validation_rejects_bad_indices(ctx):
     from parallel_reverb_raytracer_amd import capi
     tri, vert, surf = scenes.rotated_square_room(n=1)
