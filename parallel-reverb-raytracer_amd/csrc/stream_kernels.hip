@@ -435,6 +435,8 @@ __global__ __launch_bounds__(256) void bin_starts_kernel(const uint32_t * __rest
 // sums, so the chain reproduces the serial order over all shards).  Speaker channels keep the input time (kernel.cpp:530-533)
 // and share the bin, so ONE sorted list serves NCH channels of the speaker model (first_channel .. first_channel + NCH - 1);
 // the two ears of the HRTF model have their own bins (NCH = 1, one list per ear).
+// TWO lanes per bin — the even lane folds bands 0-3, the odd lane bands 4-7 (each reads its 16-byte half of the volume; both
+// read the position) — so the gather of 8 M scattered 64-byte records has twice the loads in flight per bin.
 template <bool HRTF, int NCH>
 __global__ __launch_bounds__(64) void ordered_sum_kernel(ModelDev m, uint32_t first_channel, const rvb_impulse * __restrict__ diffuse,
                                                          uint64_t ndiffuse, const rvb_impulse * __restrict__ images,
@@ -442,43 +444,45 @@ __global__ __launch_bounds__(64) void ordered_sum_kernel(ModelDev m, uint32_t fi
                                                          const uint32_t * __restrict__ starts,
                                                          uint64_t n, uint64_t nbins, float * __restrict__ hist)
 {
-    const uint64_t bin = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t t = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t bin = t >> 1;
+    const uint32_t half = (uint32_t) t & 1u;
     if (bin >= nbins)
         return;
     const uint64_t lo = starts[bin];
     if (lo == 0xFFFFFFFFull)
         return;                               // nothing lands in this bin: the histogram keeps what it holds
-    float sum[NCH][8];
+    float sum[NCH][4];
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
-        for (int b = 0; b < 8; ++b)
-            sum[c][b] = hist[((uint64_t) (first_channel + c) * 8 + b) * nbins + bin];
+        for (int b = 0; b < 4; ++b)
+            sum[c][b] = hist[((uint64_t) (first_channel + c) * 8 + half * 4 + b) * nbins + bin];
     for (uint64_t k = lo; k < n && keys[k] == (uint32_t) bin; ++k) {
         const uint64_t idx = values[k];
         const rvb_impulse * imp = idx < ndiffuse ? diffuse + idx : images + (idx - ndiffuse);
         const float4 * r = reinterpret_cast<const float4 *>(imp);
-        const float4 v0 = r[0], v1 = r[1], p = r[2];
-        const float vol[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        const float4 v = r[half], p = r[2];
+        const float vol[4] = {v.x, v.y, v.z, v.w};
         const v3 pos = mk3(p.x, p.y, p.z);      // (keyed into a bin: the volume is non-zero)
         if (HRTF) {
-            const float * t = m.table + ((uint64_t) first_channel * (360 * 180 + 1) + (uint64_t) hrtf_row(m, pos)) * 8;
+            const float * tb = m.table + ((uint64_t) first_channel * (360 * 180 + 1) + (uint64_t) hrtf_row(m, pos)) * 8 + half * 4;
 #pragma unroll
-            for (int b = 0; b < 8; ++b) sum[0][b] += vol[b] * t[b];
+            for (int b = 0; b < 4; ++b) sum[0][b] += vol[b] * tb[b];
         } else {
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const float g = speaker_gain(m, first_channel + c, pos);
 #pragma unroll
-                for (int b = 0; b < 8; ++b) sum[c][b] += vol[b] * g;
+                for (int b = 0; b < 4; ++b) sum[c][b] += vol[b] * g;
             }
         }
     }
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
-        for (int b = 0; b < 8; ++b)
-            hist[((uint64_t) (first_channel + c) * 8 + b) * nbins + bin] = sum[c][b];
+        for (int b = 0; b < 4; ++b)
+            hist[((uint64_t) (first_channel + c) * 8 + half * 4 + b) * nbins + bin] = sum[c][b];
 }
 
 __global__ __launch_bounds__(256) void flat_keys_kernel(const rvb_attenuated_impulse * __restrict__ in, uint64_t n, float sample_rate,
@@ -596,7 +600,7 @@ void rvb_launch_ordered_sum(const AttenuationModel & m, uint32_t first_channel, 
 {
     (void) nimages;
     if (nbins == 0 || n == 0) return;
-    const dim3 grid((unsigned) ((nbins + 63) / 64)), block(64);
+    const dim3 grid((unsigned) ((2 * nbins + 63) / 64)), block(64);      // two lanes per bin
     const ModelDev md = make_model(m);
 #define RVB_SUM(HRTF, NCH) hipLaunchKernelGGL((ordered_sum_kernel<HRTF, NCH>), grid, block, 0, s, md, first_channel, diffuse, ndiffuse, \
                                               images, sorted_keys, sorted_values, starts, n, nbins, hist)
