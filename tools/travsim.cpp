@@ -448,6 +448,66 @@ int main(int argc, char ** argv)
             }
         }
     }
+    // ---- K rays per quad (TRAVSIM_KRAYS=2,3,...): the wave holds 16 K rays; every iteration executes the step kind most QUADS can take
+    // part in, and a quad takes part with whichever of its rays is in that state.  Counts wave-level steps only (no switching cost).
+    if (getenv("TRAVSIM_KRAYS")) {
+        for (int K = 1; K <= atoi(getenv("TRAVSIM_KRAYS")); ++K) {
+            Sim s = base;
+            const bool use_skip = !(getenv("TRAVSIM_SKIP") && getenv("TRAVSIM_SKIP")[0] == '0');
+            unsigned long long w_node = 0, w_leaf = 0, w_done = 0, bounces = 0, a_node = 0, a_leaf = 0, a_done = 0;
+            const int R = 16 * K;
+            for (uint64_t w = 0; w < nrays; w += R) {
+                std::vector<Query> q(R); std::vector<Ray> r(R);
+                enum St { NODE, LEAF, DONE, IDLE };
+                std::vector<St> st(R, IDLE);
+                const int nq = (int) std::min<uint64_t>(R, nrays - w);
+                for (int i = 0; i < nq; ++i) {
+                    r[i].o = src; r[i].d = mk3(dirs[4 * (w + i)], dirs[4 * (w + i) + 1], dirs[4 * (w + i) + 2]); r[i].bounce = 0; r[i].alive = true;
+                    s.begin(q[i], r[i].o, r[i].d, false, 0.0f);
+                    st[i] = NODE;
+                }
+                auto classify = [&](int i) { st[i] = q[i].ref == 0xFFFFFFFFu ? DONE : ((q[i].ref & RVB_BVH_LEAF) ? LEAF : NODE); };
+                for (;;) {
+                    int cnt[3] = {0, 0, 0}, pick[3][16];
+                    for (int quad = 0; quad < 16; ++quad)
+                        for (int kind = 0; kind < 3; ++kind) {
+                            pick[kind][quad] = -1;
+                            for (int k = 0; k < K; ++k) { const int i = quad + 16 * k; if (i < nq && st[i] == (St) kind) { pick[kind][quad] = i; break; } }
+                            cnt[kind] += pick[kind][quad] >= 0;
+                        }
+                    if (cnt[0] + cnt[1] + cnt[2] == 0) break;
+                    int act = 0;
+                    if (cnt[1] > cnt[act]) act = 1;
+                    if (cnt[2] > cnt[act]) act = 2;
+                    (act == 0 ? w_node : act == 1 ? w_leaf : w_done) += 1;
+                    (act == 0 ? a_node : act == 1 ? a_leaf : a_done) += cnt[act];
+                    for (int quad = 0; quad < 16; ++quad) {
+                        const int i = pick[act][quad];
+                        if (i < 0) continue;
+                        if (act == 0) { s.node_step(q[i]); classify(i); }
+                        else if (act == 1) { const bool f = s.leaf_step(q[i]); if (f) st[i] = DONE; else classify(i); }
+                        else {
+                            if (q[i].best_i == 0xFFFFFFFFu) { st[i] = IDLE; continue; }
+                            ++bounces;
+                            const TriShade & sh = s.bs.shade[q[i].best_i];
+                            const v3 n = mk3(sh.n[0], sh.n[1], sh.n[2]);
+                            const v3 pnt = r[i].o + r[i].d * q[i].best_t;
+                            const float thr = fmaf(sh.skip_b, q[i].best_t, sh.skip_a), cosine = fabsf(dot3(n, r[i].d));
+                            r[i].d = reflect3(n, r[i].d);
+                            r[i].o = pnt;
+                            if (++r[i].bounce >= nrefl) { st[i] = IDLE; continue; }
+                            s.begin(q[i], r[i].o, r[i].d, false, 0.0f);
+                            if (use_skip && cosine > thr) q[i].skip = sh.skip_ref;
+                            st[i] = NODE;
+                        }
+                    }
+                }
+            }
+            const double wn = 16.0 * w_node / bounces, wl = 16.0 * w_leaf / bounces, wd = 16.0 * w_done / bounces;
+            printf("K %d rays per quad | per 16 ray-bounces: wave node %.2f leaf %.2f done %.2f | quads active node %.1f leaf %.1f done %.1f | cost %.0f\n",
+                   K, wn, wl, wd, (double) a_node / w_node, (double) a_leaf / w_leaf, (double) a_done / w_done, wn * C_NODE + wl * C_LEAF + wd * C_DONE);
+        }
+    }
     if (verify) printf("verify: %llu closest-hit queries against brute force, %llu mismatches; %llu any-hit (shadow) queries, %llu mismatches\n",
                        verified, mismatches, verified_any, mismatches_any);
     return 0;
