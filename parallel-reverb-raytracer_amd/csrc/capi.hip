@@ -68,6 +68,9 @@ struct rvb_ctx {
     uint64_t npairs = 1, traced_rays = 0, ir_pair = 0;
     std::vector<float> pair_mics_host;          // [npairs][3]
     DevBuf pair_geom, pair_direct, pair_range;   // device: mics+sources [2*npairs] float4, direct [npairs] Impulse, ranges [npairs][2]
+    void * pair_stage = nullptr;                 // pinned staging of the per-pair geometry of a launch
+    size_t pair_stage_cap = 0;
+    hipEvent_t pair_stage_free = nullptr;
     std::vector<rvb_impulse> pair_direct_host;
     std::vector<uint32_t> pair_range_host;
     DevBuf impulses, early, candidates, small, stamps, sort_keys, sort_scratch, sort_order, group_temp;       // small: [0] candidate count, [2..3] executed, [16..] direct, range
@@ -226,6 +229,8 @@ void rvb_destroy(rvb_ctx * ctx)
         for (int i = 0; i < 2; ++i) { if (l.pinned[i]) (void) hipHostFree(l.pinned[i]); if (l.done[i]) (void) hipEventDestroy(l.done[i]); }
         if (l.stream) (void) hipStreamDestroy(l.stream);
     }
+    if (ctx->pair_stage) (void) hipHostFree(ctx->pair_stage);
+    if (ctx->pair_stage_free) (void) hipEventDestroy(ctx->pair_stage_free);
     for (hipEvent_t e : ctx->event_pool) (void) hipEventDestroy(e);
     if (ctx->path_done) (void) hipEventDestroy(ctx->path_done);
     if (ctx->side_done) (void) hipEventDestroy(ctx->side_done);
@@ -396,17 +401,29 @@ static int trace_common(rvb_ctx * ctx, const float * mics, const float * sources
     a.time_range = reinterpret_cast<uint32_t *>(ctx->small.as<char>() + kSmallTraceRange);
     if (npairs > 1) {
         // several pairs per launch: geometry, direct path and time range per pair live in arrays of their own
-        std::vector<float> geom(8 * npairs, 0.0f);
+        // staged through pinned memory and copied in stream order: no host synchronisation in front of the launch (the staging
+        // block is reused only after the copies of the previous launch have left it)
+        const size_t geom_floats = 8 * npairs, init_words = 2 * npairs;
+        const size_t stage_bytes = geom_floats * sizeof(float) + init_words * sizeof(uint32_t);
+        if (stage_bytes > ctx->pair_stage_cap) {
+            if (ctx->pair_stage) { RVB_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void) hipHostFree(ctx->pair_stage); ctx->pair_stage = nullptr; ctx->pair_stage_cap = 0; }
+            RVB_HIP(ctx, hipHostMalloc(&ctx->pair_stage, stage_bytes, hipHostMallocDefault));
+            ctx->pair_stage_cap = stage_bytes;
+        }
+        if (!ctx->pair_stage_free) RVB_HIP(ctx, hipEventCreateWithFlags(&ctx->pair_stage_free, hipEventDisableTiming));
+        else RVB_HIP(ctx, hipEventSynchronize(ctx->pair_stage_free));
+        float * geom = static_cast<float *>(ctx->pair_stage);
+        uint32_t * init = reinterpret_cast<uint32_t *>(geom + geom_floats);
+        std::memset(geom, 0, geom_floats * sizeof(float));
         for (uint64_t p = 0; p < npairs; ++p)
             for (int i = 0; i < 3; ++i) { geom[4 * p + i] = mics[3 * p + i]; geom[4 * (npairs + p) + i] = sources[3 * p + i]; }
-        RVB_HIP(ctx, ctx->pair_geom.ensure(geom.size() * sizeof(float)));
+        for (uint64_t p = 0; p < npairs; ++p) { init[2 * p] = 0xFFFFFFFFu; init[2 * p + 1] = 0u; }
+        RVB_HIP(ctx, ctx->pair_geom.ensure(geom_floats * sizeof(float)));
         RVB_HIP(ctx, ctx->pair_direct.ensure(npairs * sizeof(rvb_impulse)));
         RVB_HIP(ctx, ctx->pair_range.ensure(npairs * 2 * sizeof(uint32_t)));
-        RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));                      // geom is a stack-local staging vector
-        RVB_HIP(ctx, hipMemcpy(ctx->pair_geom.p, geom.data(), geom.size() * sizeof(float), hipMemcpyHostToDevice));
-        std::vector<uint32_t> init(2 * npairs);
-        for (uint64_t p = 0; p < npairs; ++p) { init[2 * p] = 0xFFFFFFFFu; init[2 * p + 1] = 0u; }
-        RVB_HIP(ctx, hipMemcpy(ctx->pair_range.p, init.data(), init.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        RVB_HIP(ctx, hipMemcpyAsync(ctx->pair_geom.p, geom, geom_floats * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        RVB_HIP(ctx, hipMemcpyAsync(ctx->pair_range.p, init, init_words * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        RVB_HIP(ctx, hipEventRecord(ctx->pair_stage_free, ctx->stream));
         a.pair_mics = ctx->pair_geom.as<float4>();
         a.pair_sources = ctx->pair_geom.as<float4>() + npairs;
         a.direct = ctx->pair_direct.as<rvb_impulse>();
