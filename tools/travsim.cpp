@@ -508,6 +508,63 @@ int main(int argc, char ** argv)
                    K, wn, wl, wd, (double) a_node / w_node, (double) a_leaf / w_leaf, (double) a_done / w_done, wn * C_NODE + wl * C_LEAF + wd * C_DONE);
         }
     }
+    // ---- a POOL of R rays per wave (TRAVSIM_POOL=R): any quad takes any ray; every iteration executes the step kind most rays wait for,
+    // with up to 16 of them.  Counts wave-level steps only (no cost for moving ray state in and out of the quads).
+    if (getenv("TRAVSIM_POOL")) {
+        for (int R : {16, 24, 32, 48, 64}) {
+            if (R > atoi(getenv("TRAVSIM_POOL"))) break;
+            Sim s = base;
+            const bool use_skip = !(getenv("TRAVSIM_SKIP") && getenv("TRAVSIM_SKIP")[0] == '0');
+            unsigned long long w_step[3] = {0, 0, 0}, a_step[3] = {0, 0, 0}, bounces = 0;
+            for (uint64_t w = 0; w < nrays; w += R) {
+                std::vector<Query> q(R); std::vector<Ray> r(R);
+                enum St { NODE, LEAF, DONE, IDLE };
+                std::vector<St> st(R, IDLE);
+                const int nq = (int) std::min<uint64_t>(R, nrays - w);
+                for (int i = 0; i < nq; ++i) {
+                    r[i].o = src; r[i].d = mk3(dirs[4 * (w + i)], dirs[4 * (w + i) + 1], dirs[4 * (w + i) + 2]); r[i].bounce = 0; r[i].alive = true;
+                    s.begin(q[i], r[i].o, r[i].d, false, 0.0f);
+                    st[i] = NODE;
+                }
+                auto classify = [&](int i) { st[i] = q[i].ref == 0xFFFFFFFFu ? DONE : ((q[i].ref & RVB_BVH_LEAF) ? LEAF : NODE); };
+                for (;;) {
+                    int cnt[3] = {0, 0, 0};
+                    for (int i = 0; i < nq; ++i) if (st[i] != IDLE) ++cnt[st[i]];
+                    if (cnt[0] + cnt[1] + cnt[2] == 0) break;
+                    int act = 0;
+                    if (cnt[1] > cnt[act]) act = 1;
+                    if (cnt[2] > cnt[act]) act = 2;
+                    int taken = 0;
+                    ++w_step[act];
+                    for (int i = 0; i < nq && taken < 16; ++i) {
+                        if (st[i] != (St) act) continue;
+                        ++taken;
+                        if (act == 0) { s.node_step(q[i]); classify(i); }
+                        else if (act == 1) { const bool f = s.leaf_step(q[i]); if (f) st[i] = DONE; else classify(i); }
+                        else {
+                            if (q[i].best_i == 0xFFFFFFFFu) { st[i] = IDLE; continue; }
+                            ++bounces;
+                            const TriShade & sh = s.bs.shade[q[i].best_i];
+                            const v3 n = mk3(sh.n[0], sh.n[1], sh.n[2]);
+                            const v3 pnt = r[i].o + r[i].d * q[i].best_t;
+                            const float thr = fmaf(sh.skip_b, q[i].best_t, sh.skip_a), cosine = fabsf(dot3(n, r[i].d));
+                            r[i].d = reflect3(n, r[i].d);
+                            r[i].o = pnt;
+                            if (++r[i].bounce >= nrefl) { st[i] = IDLE; continue; }
+                            s.begin(q[i], r[i].o, r[i].d, false, 0.0f);
+                            if (use_skip && cosine > thr) q[i].skip = sh.skip_ref;
+                            st[i] = NODE;
+                        }
+                    }
+                    a_step[act] += taken;
+                }
+            }
+            const double wn = 16.0 * w_step[0] / bounces, wl = 16.0 * w_step[1] / bounces, wd = 16.0 * w_step[2] / bounces;
+            printf("pool of %d rays | per 16 ray-bounces: wave node %.2f leaf %.2f done %.2f | quads active node %.1f leaf %.1f done %.1f | cost %.0f\n",
+                   R, wn, wl, wd, (double) a_step[0] / w_step[0], (double) a_step[1] / w_step[1], (double) a_step[2] / w_step[2],
+                   wn * C_NODE + wl * C_LEAF + wd * C_DONE);
+        }
+    }
     if (verify) printf("verify: %llu closest-hit queries against brute force, %llu mismatches; %llu any-hit (shadow) queries, %llu mismatches\n",
                        verified, mismatches, verified_any, mismatches_any);
     return 0;
