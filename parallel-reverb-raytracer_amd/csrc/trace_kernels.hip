@@ -720,188 +720,6 @@ __global__ __launch_bounds__(WAVE, 8) void path_kernel(TraceArgs a)
         atomicAdd(a.executed, (unsigned long long) job.index);
 }
 
-// ---- path_kernel with a POOL of rays per wave (experiment, RVB_PATH_POOL=R) ------------------------------------------------
-// The wave owns R > 16 rays whose state lives in LDS; every iteration executes the step kind most of the pool's rays wait for,
-// with UP TO 16 of them, each taken by whichever quad comes next (any quad, any ray).  A quad therefore idles only when fewer
-// than 16 rays want the voted step, instead of whenever ITS ray wants another one (host replay, tools/travsim.cpp TRAVSIM_POOL:
-// 11.7 instead of 8.4 of 16 quads active per node step at R = 32, wave instructions per bounce -31 % before the cost of moving a
-// ray's state between LDS and the quad).  Same arithmetic, same records as path_kernel.
-#define POOL_STRIDE 36u        // dwords per ray: 7 chunks of 4 + 8 of padding (144 bytes: neighbouring rays start on different banks)
-
-template <bool SURF_LDS>
-__global__ __launch_bounds__(WAVE) void path_pool_kernel(TraceArgs a, uint32_t R)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];       // stack [stack_entries][R] | state [R][POOL_STRIDE] | slots [16] | surfaces
-    const uint32_t IDLE = 0xFFFFFFFEu;
-    const uint32_t lane = threadIdx.x, c = lane & 3u, q = lane >> 2;
-    const uint32_t state_off = a.stack_entries * R, slots_off = state_off + R * POOL_STRIDE;
-    const lds_float4_ptr surf_lds = stage_surfaces(a, lds + slots_off + 16u);
-#define ST4(ray, k) (*reinterpret_cast<float4 *>(lds + state_off + (ray) * POOL_STRIDE + 4u * (k)))
-#define STW(ray, w) (lds[state_off + (ray) * POOL_STRIDE + (w)])
-    // chunk 0: ix iy iz oix | 1: oiy oiz best_t skip | 2: ref sp best_i index | 3: o.xyz distance | 4: d.xyz tag (pair + 1, bit 31 = unit) | 5, 6: volume
-    const uint64_t first_ray = (uint64_t) blockIdx.x * R;
-    if (lane < R) {
-        const uint64_t ray = first_ray + lane;
-        uint32_t ref = IDLE;
-        if (ray < a.nrays) {
-            uint32_t pair = 0, local = (uint32_t) ray;
-            v3 source = ld3(a.source);
-            if (a.npairs > 1) {
-                pair = (uint32_t) ray / a.rays_per_pair;
-                local = (uint32_t) ray - pair * a.rays_per_pair;
-                const float4 s4 = a.pair_sources[pair];
-                source = mk3(s4.x, s4.y, s4.z);
-            }
-            const float4 d4 = a.directions[local];
-            const float len2 = d4.x * d4.x + d4.y * d4.y + d4.z * d4.z;
-            const float ix = clamp_inv(d4.x), iy = clamp_inv(d4.y), iz = clamp_inv(d4.z);
-            ST4(lane, 0) = make_float4(ix, iy, iz, source.x * ix);
-            ST4(lane, 1) = make_float4(source.y * iy, source.z * iz, __builtin_inff(), __uint_as_float(RVB_BVH_EMPTY));
-            ST4(lane, 3) = make_float4(source.x, source.y, source.z, 0.0f);
-            ST4(lane, 4) = make_float4(d4.x, d4.y, d4.z, __uint_as_float((pair + 1u) | (fabsf(len2 - 1.0f) < 1e-3f ? 0x80000000u : 0u)));
-            ST4(lane, 5) = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-            ST4(lane, 6) = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-            ref = a.nreflections ? 0u : IDLE;
-        }
-        ST4(lane, 2) = make_float4(__uint_as_float(ref), __uint_as_float(0u), __uint_as_float(NONE), __uint_as_float(0u));
-    }
-    const uint32_t lane_base4 = (lane & 60u) << 2;
-    const uint32_t lane_bit = 1u << c, lt_mask = lane_bit - 1u;
-    const char * node_base = reinterpret_cast<const char *>(a.scene.nodes);
-    const char * tri_base = reinterpret_cast<const char *>(a.scene.tris);
-    const uint32_t child_off = 16u * c;
-    const float neg_cull = -a.scene.cull_abs, cull_scale = 1.0f + a.scene.cull_rel;
-    const unsigned long long NO_HIT_KEY = (0x7F800000ull << 32) | NONE;
-    for (;;) {
-        __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): the state written by the previous step
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t rref = lane < R ? STW(lane, 8) : IDLE;
-        const unsigned long long m_node = __builtin_amdgcn_ballot_w64((int32_t) rref >= 0);
-        const unsigned long long m_done = __builtin_amdgcn_ballot_w64(rref == NONE);
-        const unsigned long long m_leaf = __builtin_amdgcn_ballot_w64((int32_t) rref < (int32_t) IDLE);
-        const int n_node = scalar_popcount(m_node), n_done = scalar_popcount(m_done), n_leaf = scalar_popcount(m_leaf);
-        if ((n_node | n_done | n_leaf) == 0)
-            break;
-        const int kind = (n_node >= n_leaf && n_node >= n_done) ? 0 : (n_leaf >= n_done ? 1 : 2);
-        const unsigned long long mask = kind == 0 ? m_node : (kind == 1 ? m_leaf : m_done);
-        const int n_kind = kind == 0 ? n_node : (kind == 1 ? n_leaf : n_done);
-        // the first 16 rays of the voted kind, one per quad
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
-        if (((mask >> lane) & 1ull) && rank < 16u)
-            lds[slots_off + rank] = lane;
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_wave_barrier();
-        const bool active = q < (uint32_t) (n_kind < 16 ? n_kind : 16);
-        if (!active)
-            continue;
-        const uint32_t me = lds[slots_off + q];
-        if (kind == 0) {
-            const float4 f0 = ST4(me, 0), f1 = ST4(me, 1);
-            uint32_t ref = STW(me, 8), sp = STW(me, 9);
-            const uint4 n = *reinterpret_cast<const uint4 *>(node_base + (ref | child_off));
-            const float limit = fmaf(f1.z, cull_scale, a.scene.cull_abs);
-            float tn;
-            const bool ok = slab(n, f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, limit, neg_cull, __float_as_uint(f1.w), tn);
-            const uint32_t cref = n.w;
-            const uint32_t key = ok ? ((__float_as_uint(fmaxf(tn, 0.0f)) & ~3u) | c) : NONE;
-            uint32_t kmin = min(key, dpp_u<QP_SWAP1>(key));
-            kmin = min(kmin, dpp_u<QP_SWAP2>(kmin));
-            if (kmin == NONE) {
-                if (sp > 0) { --sp; ref = lds[sp * R + me]; } else ref = NONE;
-            } else {
-                const uint32_t winner = kmin & 3u;
-                uint32_t okmask = ok ? lane_bit : 0u;
-                okmask |= dpp_u<QP_SWAP1>(okmask);
-                okmask |= dpp_u<QP_SWAP2>(okmask);
-                const uint32_t rest = okmask & ~(1u << winner);
-                if (ok && c != winner)
-                    lds[(sp + __popc(rest & lt_mask)) * R + me] = cref;
-                sp += __popc(rest);
-                ref = (uint32_t) __builtin_amdgcn_ds_bpermute((int) (lane_base4 + (winner << 2)), (int) cref);
-            }
-            if (c == 0) { STW(me, 8) = ref; STW(me, 9) = sp; }
-        } else if (kind == 1) {
-            const float4 f3 = ST4(me, 3), f4 = ST4(me, 4);
-            uint32_t ref = STW(me, 8), sp = STW(me, 9);
-            unsigned long long best_key = ((unsigned long long) STW(me, 6) << 32) | STW(me, 10);
-            const v3 o = mk3(f3.x, f3.y, f3.z), d = mk3(f4.x, f4.y, f4.z);
-            const uint32_t first = ref & 0x0FFFFFFFu;
-            const uint32_t count = ((ref >> 28) & 7u) + 1u;
-            float dist = 0.0f;
-            uint32_t idx = NONE;
-            if (c < count) {
-                const float4 * tp = reinterpret_cast<const float4 *>(tri_base + tri_byte_offset(first + c));
-                float4 ta = tp[0], tb = tp[1], tc = tp[2];
-                asm volatile("" : "+v"(ta.x), "+v"(tb.x), "+v"(tc.x));
-                dist = mt_intersect(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), o, d);
-                idx = __float_as_uint(tc.y);
-            }
-            const bool valid = c < count && dist > RVB_EPSILON;
-            unsigned long long key = valid ? (((unsigned long long) __float_as_uint(dist) << 32) | idx) : NO_HIT_KEY;
-            key = min_u64(key, dpp_u64<QP_SWAP1>(key));
-            key = min_u64(key, dpp_u64<QP_SWAP2>(key));
-            best_key = min_u64(best_key, key);
-            if (sp > 0) { --sp; ref = lds[sp * R + me]; } else ref = NONE;
-            if (c == 0) { STW(me, 6) = (uint32_t) (best_key >> 32); STW(me, 8) = ref; STW(me, 9) = sp; STW(me, 10) = (uint32_t) best_key; }
-        } else {
-            const float4 f3 = ST4(me, 3), f4 = ST4(me, 4);
-            const uint32_t best_i = STW(me, 10), index = STW(me, 11);
-            const float best_t = __uint_as_float(STW(me, 6));
-            const uint32_t tag = __float_as_uint(f4.w);
-            const uint32_t ray = (uint32_t) first_ray + me;
-            if (best_i == NONE) {                                  // kernel.cpp:372-375: the ray escaped; its remaining slots read zero
-                for (uint32_t i = index; i < a.nreflections; ++i) {
-                    const uint64_t record = (uint64_t) ray * a.nreflections + i;
-                    store_stream(reinterpret_cast<float4 *>(a.impulses + record) + c, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-                    if (c == 1 && a.sort_keys)
-                        a.sort_keys[record] = NONE;
-                }
-                if (c == 0) { atomicAdd(a.executed, (unsigned long long) index); STW(me, 8) = IDLE; }
-                continue;
-            }
-            const v3 o = mk3(f3.x, f3.y, f3.z), d = mk3(f4.x, f4.y, f4.z);
-            const float4 * shade = reinterpret_cast<const float4 *>(a.scene.shade + best_i);
-            const float4 sh = shade[0], sk = shade[1];
-            const v3 normal = mk3(sh.x, sh.y, sh.z);
-            const uint32_t surface = __float_as_uint(sh.w);
-            const uint32_t half = c & 1u;
-            float4 sp4;
-            if (SURF_LDS) sp4 = lds_load4(surf_lds, 4 * surface + half);
-            else sp4 = reinterpret_cast<const float4 *>(a.scene.surfaces + surface)[half];
-            float4 vol = ST4(me, 5u + half);
-            const v3 p = o + d * best_t;                                  // kernel.cpp:459
-            const float new_dist = f3.w + best_t;                         // kernel.cpp:460
-            vol = make_float4(-vol.x * sp4.x, -vol.y * sp4.y, -vol.z * sp4.z, -vol.w * sp4.w);   // kernel.cpp:461
-            const float diff = fabsf(dot3(normal, d));                    // kernel.cpp:478
-            const float threshold = (tag & 0x80000000u) ? fmaf(sk.z, best_t, sk.y) : __builtin_inff();
-            const uint32_t skip = diff > threshold ? __float_as_uint(sk.x) : RVB_BVH_EMPTY;
-            float4 chunk = vol;
-            if (c == 2) chunk = make_float4(p.x, p.y, p.z, diff);
-            else if (c == 3) chunk = make_float4(new_dist, threshold, __uint_as_float(best_i), __uint_as_float(tag & 0x7FFFFFFFu));
-            const uint64_t record = (uint64_t) ray * a.nreflections + index;
-            store_stream(reinterpret_cast<float4 *>(a.impulses + record) + c, chunk);
-            if (c == 0 && index < RVB_NUM_IMAGE_SOURCE - 1)
-                a.early[ray * (RVB_NUM_IMAGE_SOURCE - 1) + index] = best_i;
-            if (c == 1 && a.sort_keys)
-                a.sort_keys[record] = a.scene.leafpos[best_i];
-            const v3 nd = reflect3(normal, d);                            // kernel.cpp:492-499
-            const bool more = index + 1u < a.nreflections;
-            if (c < 2) ST4(me, 5u + half) = vol;
-            if (c == 0) {
-                const float ix = clamp_inv(nd.x), iy = clamp_inv(nd.y), iz = clamp_inv(nd.z);
-                ST4(me, 0) = make_float4(ix, iy, iz, p.x * ix);
-                ST4(me, 1) = make_float4(p.y * iy, p.z * iz, __builtin_inff(), __uint_as_float(skip));
-                ST4(me, 2) = make_float4(__uint_as_float(more ? 0u : IDLE), __uint_as_float(0u), __uint_as_float(NONE), __uint_as_float(index + 1u));
-                ST4(me, 3) = make_float4(p.x, p.y, p.z, new_dist);
-                ST4(me, 4) = make_float4(nd.x, nd.y, nd.z, f4.w);
-                if (!more) atomicAdd(a.executed, (unsigned long long) (index + 1u));
-            }
-        }
-    }
-#undef ST4
-#undef STW
-}
-
 // reference kernel.cpp:243-265 (add_image) for a known-valid slot
 __device__ __forceinline__ void make_image(const TraceArgs & a, v3 mic, v3 mic_reflection, v3 source,
                                            const float volume[8], rvb_impulse & out)
@@ -1237,14 +1055,6 @@ uint32_t rvb_lds_surfaces(uint32_t stack_entries, uint64_t nsurfaces)
 void rvb_launch_path(const TraceArgs & a, hipStream_t s)
 {
     if (a.nrays == 0) return;
-    static const uint32_t pool = getenv("RVB_PATH_POOL") ? (uint32_t) atoi(getenv("RVB_PATH_POOL")) : 0u;
-    if (pool >= 16 && pool <= 64 && pool % 4 == 0) {       // experiment: a pool of `pool` rays per wave (path_pool_kernel)
-        const unsigned blocks = (unsigned) ((a.nrays + pool - 1) / pool);
-        const size_t lds = ((size_t) a.stack_entries * pool + (size_t) pool * POOL_STRIDE + 16u) * sizeof(uint32_t) + (size_t) a.lds_surfaces * sizeof(rvb_surface);
-        if (a.lds_surfaces) hipLaunchKernelGGL(path_pool_kernel<true>, dim3(blocks), dim3(WAVE), lds, s, a, pool);
-        else hipLaunchKernelGGL(path_pool_kernel<false>, dim3(blocks), dim3(WAVE), lds, s, a, pool);
-        return;
-    }
     const unsigned blocks = (unsigned) ((a.nrays + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK);
     if (a.lds_surfaces) hipLaunchKernelGGL(path_kernel<true>, dim3(blocks), dim3(WAVE), quad_kernel_lds_bytes(a), s, a);
     else hipLaunchKernelGGL(path_kernel<false>, dim3(blocks), dim3(WAVE), quad_kernel_lds_bytes(a), s, a);
