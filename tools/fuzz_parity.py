@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Developer tool: a longer randomized parity campaign than the test suite runs — HIP path against the brute-force CPU oracle,
 bit for bit, on random triangle soups (duplicates, coplanar overlaps, degenerate and non-finite triangles), tessellated rooms of
-random resolution, random source / microphone positions, ray counts and reflection counts.    python tools/fuzz_parity.py [cases]"""
+random resolution, random source / microphone positions, ray counts and reflection counts.    python tools/fuzz_parity.py [cases] [gpu]
+With `gpu` the checker is the oracle source compiled for the GPU (oracle/gpu_oracle.hip, one thread per ray, brute force), which
+affords scenes of tens of thousands of triangles and tens of thousands of rays per case."""
 import os
 import sys
 import time
@@ -27,8 +29,10 @@ def same(a, b):
 
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-    rng = np.random.default_rng(2026)
-    ctx, oracle = capi.Context(0), pyoracle.Oracle("port")
+    big = len(sys.argv) > 2 and sys.argv[2] == "gpu"
+    rng = np.random.default_rng(2026 + (1 if big else 0))
+    ctx = capi.Context(0)                                   # (the product library loads before the GPU build of the oracle)
+    oracle, port = pyoracle.Oracle("gpu" if big else "port"), pyoracle.Oracle("port")
     impulses = images = bad = 0
     t0 = time.perf_counter()
     for case in range(cases):
@@ -36,17 +40,17 @@ def main():
         if kind == 0:
             scene, extent = triangle_soup(1000 + case), 4.0
         elif kind == 1:
-            scene, extent = scenes.rotated_square_room(n=int(rng.integers(1, 12))), 10.0
+            scene, extent = scenes.rotated_square_room(n=int(rng.integers(1, 60 if big else 12))), 10.0
         else:
-            scene, extent = scenes.cathedral(int(rng.integers(600, 5000)))[0], 9.0
+            scene, extent = scenes.cathedral(int(rng.integers(600, 40000 if big else 5000)))[0], 9.0
         mic = rng.uniform(-extent, extent, 3) * (0.3, 0.1, 0.3) + (0, 2.0 if kind else 0.0, 0)
         src = rng.uniform(-extent, extent, 3) * (0.3, 0.1, 0.3) + (0, 2.5 if kind else 0.0, 0)
-        nrays, nrefl = int(rng.integers(1, 3000)), int(rng.integers(1, 40))
+        nrays, nrefl = int(rng.integers(1, 30000 if big else 3000)), int(rng.integers(1, 120 if big else 40))
         dirs = scenes.sphere_directions(nrays, seed=case + 1)
         ctx.set_scene(scene)
         ctx.raytrace(mic, src, dirs, nrefl, dtypes.AIR_COEFFICIENTS)
         want, image, index = oracle.raytrace(scene, mic, src, dirs, nrefl, dtypes.AIR_COEFFICIENTS)
-        got_images, want_images = ctx.get_raw_images(False), oracle.collect_images(image, index, False)
+        got_images, want_images = ctx.get_raw_images(False), port.collect_images(image, index, False)
         ok = same(ctx.get_raw_diffuse(), want) and got_images.shape == want_images.shape and same(got_images, want_images)
         impulses += want.shape[0]
         images += want_images.shape[0]
