@@ -97,7 +97,7 @@ struct Builder {
     // Plane patches (units) are kept whole: a node either lies inside one unit or holds whole units (and loose triangles)
     // only.  While several units share a node every triangle is binned at its UNIT's centroid, so a split never cuts a unit;
     // the node that holds exactly one unit is that unit's root (BinNode::unit_root) and splits on the triangles' own
-    // centroids from there on.  This is what makes a wall ONE child slot that a ray starting on it can skip (TriSkip).
+    // centroids from there on.  This is what makes a wall ONE child slot that a ray starting on it can skip (TriShade::skip_ref).
     int build(uint32_t first, uint32_t count, int depth, bool inside_unit = false)
     {
         BinNode node;
@@ -231,7 +231,7 @@ struct Builder {
 };
 
 
-// ---- own-plane skip (TriSkip, bvh.h) ---------------------------------------------------------------------------------
+// ---- own-plane skip (the skip fields of TriShade, bvh.h) ------------------------------------------------------------
 // Claim.  Let the ray (o, d) start on triangle T: o = fl(o_prev + d_prev * t) with t the Möller–Trumbore distance of T for
 // (o_prev, d_prev) (path_kernel), or the same stored point (shadow_kernel).  Let T' be a triangle whose three effective
 // vertices (v0, v0 + e0, v0 + e1 with the float edges the kernels use) and those of T lie within delta of one plane P, with
@@ -253,7 +253,6 @@ struct Builder {
 // with c = |dot(stored unit normal of T, d)| as the kernels compute it.  Constants carry a factor 2 over the derivation and the
 // final inequality another 1e-4 relative; TriShade::skip_a = C + A (1 + 1e-4) / EPSILON (at least 0.01), skip_b = B (1 + 1e-4) / EPSILON.
 // tools/travsim.cpp (TRAVSIM_VERIFY) checks the rule against brute force on the host, the GPU parity tests on the device.
-// TriSkip fields live in TriShade (bvh.h).
 struct PlaneGroup {
     double n[3] = {0, 0, 1}, p[3] = {0, 0, 0};      // reference plane (that of the group's largest triangle): unit normal, point
     double area = -1.0, delta = 0.0, theta = 0.0, g = 0.0, d = 0.0;
