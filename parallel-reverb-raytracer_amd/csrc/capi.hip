@@ -808,9 +808,9 @@ static int flatten_sum(rvb_ctx * ctx, const rvb_attenuated_impulse * d_in, uint6
     RVB_HIP(ctx, ctx->hist.ensure(bins * 8 * sizeof(float)));
     rvb_sort_pairs(ctx->sort_temp.p, ctx->sort_temp.cap, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(),
                    ctx->vals_a.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), n, key_bits_for(bins), ctx->stream);
-    RVB_HIP(ctx, ctx->bin_starts.ensure(bins * 4));
+    RVB_HIP(ctx, ctx->bin_starts.ensure(bins * 8));
     RVB_HIP(ctx, hipMemsetAsync(ctx->bin_starts.p, 0xFF, bins * 4, ctx->stream));
-    rvb_launch_bin_starts(ctx->keys_b.as<uint32_t>(), n, bins, ctx->bin_starts.as<uint32_t>(), ctx->stream);
+    rvb_launch_bin_starts(ctx->keys_b.as<uint32_t>(), n, bins, ctx->bin_starts.as<uint32_t>(), ctx->bin_starts.as<uint32_t>() + bins, ctx->stream);
     rvb_launch_flat_ordered_sum(d_in, ctx->keys_b.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), ctx->bin_starts.as<uint32_t>(), n, bins,
                                 ctx->hist.as<float>(), ctx->stream);
     RVB_HIP(ctx, hipGetLastError());
@@ -1158,7 +1158,7 @@ int rvb_ir_accumulate(rvb_ctx * ctx, float predelay, float sample_rate, uint64_t
         // speaker channels keep the input time (kernel.cpp:530-533): one sorted list serves them all; the two ears of the
         // HRTF model shift the time differently (kernel.cpp:616-622) and get a list each
         const uint32_t lists = m.hrtf ? m.nchannels : 1u;
-        RVB_HIP(ctx, ctx->bin_starts.ensure(nbins * 4));
+        RVB_HIP(ctx, ctx->bin_starts.ensure(nbins * 8));          // starts, then ends
         for (uint32_t ch = 0; ch < lists; ++ch) {
             rvb_launch_bin_keys(m, ch, ir_diffuse(ctx), ndiffuse, 0, predelay, sample_rate, sentinel,
                                 ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), ctx->stream);
@@ -1167,9 +1167,9 @@ int rvb_ir_accumulate(rvb_ctx * ctx, float predelay, float sample_rate, uint64_t
             rvb_sort_pairs(ctx->sort_temp.p, ctx->sort_temp.cap, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(),
                            ctx->vals_a.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), n, bits, ctx->stream);
             RVB_HIP(ctx, hipMemsetAsync(ctx->bin_starts.p, 0xFF, nbins * 4, ctx->stream));
-            rvb_launch_bin_starts(ctx->keys_b.as<uint32_t>(), n, nbins, ctx->bin_starts.as<uint32_t>(), ctx->stream);
+            rvb_launch_bin_starts(ctx->keys_b.as<uint32_t>(), n, nbins, ctx->bin_starts.as<uint32_t>(), ctx->bin_starts.as<uint32_t>() + nbins, ctx->stream);
             rvb_launch_ordered_sum(m, ch, m.hrtf ? 1u : m.nchannels, ir_diffuse(ctx), ndiffuse, ctx->images.as<rvb_impulse>(), nimages,
-                                   ctx->keys_b.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), ctx->bin_starts.as<uint32_t>(), n, nbins, hist, ctx->stream);
+                                   ctx->vals_b.as<uint32_t>(), ctx->bin_starts.as<uint32_t>(), ctx->bin_starts.as<uint32_t>() + nbins, n, nbins, hist, ctx->stream);
         }
         ctx->end_timing();
     } else {

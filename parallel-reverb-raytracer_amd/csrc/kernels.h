@@ -93,10 +93,11 @@ void rvb_launch_bin_keys(const AttenuationModel & m, uint32_t channel, const rvb
                          float predelay, float sample_rate, uint32_t sentinel, uint32_t * keys, uint32_t * values, hipStream_t s);
 void rvb_launch_ordered_sum(const AttenuationModel & m, uint32_t first_channel, uint32_t nchannels, const rvb_impulse * diffuse,
                             uint64_t ndiffuse, const rvb_impulse * images, uint64_t nimages,
-                            const uint32_t * sorted_keys, const uint32_t * sorted_values, const uint32_t * starts, uint64_t n,
+                            const uint32_t * sorted_values, const uint32_t * starts, const uint32_t * ends, uint64_t n,
                             uint64_t nbins, float * hist, hipStream_t s);
-// starts[key] = first position of `key` in the sorted list (starts[] pre-filled with 0xFFFFFFFF by the caller, nbins entries)
-void rvb_launch_bin_starts(const uint32_t * sorted_keys, uint64_t n, uint64_t nbins, uint32_t * starts, hipStream_t s);
+// starts[key] / ends[key] = first position of `key` in the sorted list / one past its last (starts[] pre-filled with 0xFFFFFFFF by
+// the caller, nbins entries each; ends[] is only read where starts[] was written)
+void rvb_launch_bin_starts(const uint32_t * sorted_keys, uint64_t n, uint64_t nbins, uint32_t * starts, uint32_t * ends, hipStream_t s);
 // flattenImpulses of already attenuated impulses (rayverb.cpp:48-77): keys + ordered sum
 void rvb_launch_flat_keys(const rvb_attenuated_impulse * in, uint64_t n, float sample_rate, uint32_t * keys, uint32_t * values,
                           uint32_t * max_time_bits, hipStream_t s);

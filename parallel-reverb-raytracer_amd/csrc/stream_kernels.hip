@@ -421,12 +421,17 @@ __global__ __launch_bounds__(256) void bin_keys_kernel(ModelDev m, uint32_t ch, 
 // Where each bin's run starts in the sorted key list: starts[key] = first position of that key (entries of absent keys keep
 // the caller's 0xFFFFFFFF fill).  One coalesced pass over the keys replaces a 23-step binary search per bin — 19 M dependent
 // random reads at workload C2, which made the summation kernel fetch 3 GB for 0.5 GB of impulses.
-__global__ __launch_bounds__(256) void bin_starts_kernel(const uint32_t * __restrict__ keys, uint64_t n, uint64_t nbins, uint32_t * __restrict__ starts)
+__global__ __launch_bounds__(256) void bin_starts_kernel(const uint32_t * __restrict__ keys, uint64_t n, uint64_t nbins, uint32_t * __restrict__ starts,
+                                                         uint32_t * __restrict__ ends)
 {
     for (uint64_t k = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t) gridDim.x * blockDim.x) {
         const uint32_t key = keys[k];
-        if (key < nbins && (k == 0 || keys[k - 1] != key))
+        if (key >= nbins)
+            continue;
+        if (k == 0 || keys[k - 1] != key)
             starts[key] = (uint32_t) k;
+        if (k + 1 == n || keys[k + 1] != key)     // (with both ends known the summation loop has no data-dependent exit: its gathers overlap)
+            ends[key] = (uint32_t) (k + 1);
     }
 }
 
@@ -435,14 +440,17 @@ __global__ __launch_bounds__(256) void bin_starts_kernel(const uint32_t * __rest
 // sums, so the chain reproduces the serial order over all shards).  Speaker channels keep the input time (kernel.cpp:530-533)
 // and share the bin, so ONE sorted list serves NCH channels of the speaker model (first_channel .. first_channel + NCH - 1);
 // the two ears of the HRTF model have their own bins (NCH = 1, one list per ear).
+#ifndef SUM_UNROLL
+#define SUM_UNROLL 4
+#endif
 // TWO lanes per bin — the even lane folds bands 0-3, the odd lane bands 4-7 (each reads its 16-byte half of the volume; both
 // read the position) — so the gather of 8 M scattered 64-byte records has twice the loads in flight per bin.
 template <bool HRTF, int NCH>
 __global__ __launch_bounds__(64) void ordered_sum_kernel(ModelDev m, uint32_t first_channel, const rvb_impulse * __restrict__ diffuse,
                                                          uint64_t ndiffuse, const rvb_impulse * __restrict__ images,
-                                                         const uint32_t * __restrict__ keys, const uint32_t * __restrict__ values,
-                                                         const uint32_t * __restrict__ starts,
-                                                         uint64_t n, uint64_t nbins, float * __restrict__ hist)
+                                                         const uint32_t * __restrict__ values,
+                                                         const uint32_t * __restrict__ starts, const uint32_t * __restrict__ ends,
+                                                         uint64_t nbins, float * __restrict__ hist)
 {
     const uint64_t t = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t bin = t >> 1;
@@ -458,23 +466,35 @@ __global__ __launch_bounds__(64) void ordered_sum_kernel(ModelDev m, uint32_t fi
 #pragma unroll
         for (int b = 0; b < 4; ++b)
             sum[c][b] = hist[((uint64_t) (first_channel + c) * 8 + half * 4 + b) * nbins + bin];
-    for (uint64_t k = lo; k < n && keys[k] == (uint32_t) bin; ++k) {
-        const uint64_t idx = values[k];
-        const rvb_impulse * imp = idx < ndiffuse ? diffuse + idx : images + (idx - ndiffuse);
-        const float4 * r = reinterpret_cast<const float4 *>(imp);
-        const float4 v = r[half], p = r[2];
-        const float vol[4] = {v.x, v.y, v.z, v.w};
-        const v3 pos = mk3(p.x, p.y, p.z);      // (keyed into a bin: the volume is non-zero)
-        if (HRTF) {
-            const float * tb = m.table + ((uint64_t) first_channel * (360 * 180 + 1) + (uint64_t) hrtf_row(m, pos)) * 8 + half * 4;
+    const uint64_t hi = ends[bin];
+    // SUM_UNROLL impulses per round: their index loads, then their record gathers, leave together; the adds stay in impulse order
+    for (uint64_t k = lo; k < hi; k += SUM_UNROLL) {
+        float4 v[SUM_UNROLL], p[SUM_UNROLL];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) sum[0][b] += vol[b] * tb[b];
-        } else {
+        for (int u = 0; u < SUM_UNROLL; ++u) {
+            const uint64_t kk = k + u < hi ? k + u : lo;
+            const uint64_t idx = values[kk];
+            const rvb_impulse * imp = idx < ndiffuse ? diffuse + idx : images + (idx - ndiffuse);
+            const float4 * r = reinterpret_cast<const float4 *>(imp);
+            v[u] = r[half];
+            p[u] = r[2];
+        }
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const float g = speaker_gain(m, first_channel + c, pos);
+        for (int u = 0; u < SUM_UNROLL; ++u) {
+            if (k + u >= hi) break;
+            const float vol[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            const v3 pos = mk3(p[u].x, p[u].y, p[u].z);      // (keyed into a bin: the volume is non-zero)
+            if (HRTF) {
+                const float * tb = m.table + ((uint64_t) first_channel * (360 * 180 + 1) + (uint64_t) hrtf_row(m, pos)) * 8 + half * 4;
 #pragma unroll
-                for (int b = 0; b < 4; ++b) sum[c][b] += vol[b] * g;
+                for (int b = 0; b < 4; ++b) sum[0][b] += vol[b] * tb[b];
+            } else {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const float g = speaker_gain(m, first_channel + c, pos);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) sum[c][b] += vol[b] * g;
+                }
             }
         }
     }
@@ -595,7 +615,7 @@ void rvb_launch_bin_keys(const AttenuationModel & m, uint32_t channel, const rvb
 
 void rvb_launch_ordered_sum(const AttenuationModel & m, uint32_t first_channel, uint32_t nchannels, const rvb_impulse * diffuse,
                             uint64_t ndiffuse, const rvb_impulse * images, uint64_t nimages,
-                            const uint32_t * sorted_keys, const uint32_t * sorted_values, const uint32_t * starts, uint64_t n,
+                            const uint32_t * sorted_values, const uint32_t * starts, const uint32_t * ends, uint64_t n,
                             uint64_t nbins, float * hist, hipStream_t s)
 {
     (void) nimages;
@@ -603,7 +623,7 @@ void rvb_launch_ordered_sum(const AttenuationModel & m, uint32_t first_channel, 
     const dim3 grid((unsigned) ((2 * nbins + 63) / 64)), block(64);      // two lanes per bin
     const ModelDev md = make_model(m);
 #define RVB_SUM(HRTF, NCH) hipLaunchKernelGGL((ordered_sum_kernel<HRTF, NCH>), grid, block, 0, s, md, first_channel, diffuse, ndiffuse, \
-                                              images, sorted_keys, sorted_values, starts, n, nbins, hist)
+                                              images, sorted_values, starts, ends, nbins, hist)
     if (m.hrtf) { RVB_SUM(true, 1); return; }
     switch (nchannels) {                       // speaker channels of one sorted list
     case 1: RVB_SUM(false, 1); break;
@@ -613,7 +633,7 @@ void rvb_launch_ordered_sum(const AttenuationModel & m, uint32_t first_channel, 
     default:                                   // more than four: in groups (64 accumulators per lane would spill)
         for (uint32_t c = 0; c < nchannels; c += 4) {
             const uint32_t k = nchannels - c < 4 ? nchannels - c : 4;
-            rvb_launch_ordered_sum(m, first_channel + c, k, diffuse, ndiffuse, images, nimages, sorted_keys, sorted_values, starts, n, nbins, hist, s);
+            rvb_launch_ordered_sum(m, first_channel + c, k, diffuse, ndiffuse, images, nimages, sorted_values, starts, ends, n, nbins, hist, s);
         }
     }
 #undef RVB_SUM
@@ -640,10 +660,10 @@ void rvb_launch_flat_ordered_sum(const rvb_attenuated_impulse * in, const uint32
                        sorted_values, starts, n, nbins, out);
 }
 
-void rvb_launch_bin_starts(const uint32_t * sorted_keys, uint64_t n, uint64_t nbins, uint32_t * starts, hipStream_t s)
+void rvb_launch_bin_starts(const uint32_t * sorted_keys, uint64_t n, uint64_t nbins, uint32_t * starts, uint32_t * ends, hipStream_t s)
 {
     if (n == 0) return;
-    hipLaunchKernelGGL(bin_starts_kernel, dim3(stream_blocks(n, 256)), dim3(256), 0, s, sorted_keys, n, nbins, starts);
+    hipLaunchKernelGGL(bin_starts_kernel, dim3(stream_blocks(n, 256)), dim3(256), 0, s, sorted_keys, n, nbins, starts, ends);
 }
 
 size_t rvb_sort_temp_bytes(uint64_t n)
