@@ -511,7 +511,7 @@ int main(int argc, char ** argv)
     // ---- a POOL of R rays per wave (TRAVSIM_POOL=R): any quad takes any ray; every iteration executes the step kind most rays wait for,
     // with up to 16 of them.  Counts wave-level steps only (no cost for moving ray state in and out of the quads).
     if (getenv("TRAVSIM_POOL")) {
-        for (int R : {16, 24, 32, 48, 64}) {
+        for (int R : {12, 13, 14, 15, 16, 24, 32, 48, 64}) {
             if (R > atoi(getenv("TRAVSIM_POOL"))) break;
             Sim s = base;
             const bool use_skip = !(getenv("TRAVSIM_SKIP") && getenv("TRAVSIM_SKIP")[0] == '0');
