@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool: per-kernel timings of the BASELINE.json configurations other than the bench line's (C3 per-GPU share,
-C4, C5) on one GPU — the numbers DESIGN.md quotes for them.  Same code path as bench.py (fused IR, fast histogram).
-    python tools/config_bench.py > gpurun_out/config_bench.json"""
+C4, C5) on one GPU — the numbers DESIGN.md quotes for them.  Same code path as bench.py (fused IR); the histogram mode is the
+bench's default (exact) unless `fast` is given.    python tools/config_bench.py [fast] > gpurun_out/config_bench.json"""
 import json
 import os
 import sys
@@ -16,6 +16,8 @@ import rvb_import  # noqa: E402
 rvb_import.load()
 import torch  # noqa: E402
 from parallel_reverb_raytracer_amd import capi, dtypes, scenes  # noqa: E402
+
+MODE = capi.IR_FAST if (len(sys.argv) > 1 and sys.argv[1] == "fast") else capi.IR_EXACT
 
 
 def run(name, scene, mic, src, nrays, nrefl, model, steps=4):
@@ -44,7 +46,7 @@ def run(name, scene, mic, src, nrays, nrefl, model, steps=4):
         range_t = dict(ctx.last_timings())
         nbins = ctx.ir_bins(hi, lo, 44100.0)
         hist = torch.zeros((2, 8, nbins), device="cuda", dtype=torch.float32)
-        ctx.ir_accumulate_tensor(lo, 44100.0, nbins, capi.IR_FAST, hist)
+        ctx.ir_accumulate_tensor(lo, 44100.0, nbins, MODE, hist)
         ctx.synchronize()
         acc_t = dict(ctx.last_timings())
         if it:                                   # first iteration allocates
@@ -80,7 +82,7 @@ def pairs_pipelined(scene, src, mic, nrays, nrefl, npairs):
         facing = facing / np.linalg.norm(facing)
         return ((mic[p], src[p], nrefl, dtypes.AIR_COEFFICIENTS),
                 dict(model=distributed.HrtfModel(table, facing, (0, 1, 0)), sample_rate=44100.0, trim_predelay=True,
-                     mode=capi.IR_FAST, device=device))
+                     mode=MODE, device=device))
 
     jobs = [job(p) for p in range(npairs)]
     out = {}
@@ -104,10 +106,10 @@ def pairs_pipelined(scene, src, mic, nrays, nrefl, npairs):
         return distributed.HrtfModel(table, facing / np.linalg.norm(facing), (0, 1, 0))
 
     for per_launch in (4, 8):
-        distributed.generate_pair_irs(ctxs, pair_list, nrefl, dtypes.AIR_COEFFICIENTS, model_for, 44100.0, device=device, pairs_per_launch=per_launch)
+        distributed.generate_pair_irs(ctxs, pair_list, nrefl, dtypes.AIR_COEFFICIENTS, model_for, 44100.0, device=device, pairs_per_launch=per_launch, mode=MODE)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        distributed.generate_pair_irs(ctxs, pair_list, nrefl, dtypes.AIR_COEFFICIENTS, model_for, 44100.0, device=device, pairs_per_launch=per_launch)
+        distributed.generate_pair_irs(ctxs, pair_list, nrefl, dtypes.AIR_COEFFICIENTS, model_for, 44100.0, device=device, pairs_per_launch=per_launch, mode=MODE)
         torch.cuda.synchronize()
         out["%d_pairs_per_launch_ms_per_pair" % per_launch] = (time.perf_counter() - t0) * 1e3 / npairs
     for c in ctxs:
