@@ -206,6 +206,8 @@ def main():
     for c in contexts:
         distributed.generate_ir(c, *trace_args, **ir_kwargs(None))
     fence()
+    for c in contexts:
+        c.set_concurrent_traces(1)                  # alone on the GPU: what a caller with one IR gets (the pipeline announced its group)
     solo_irs = 4
     t0 = time.perf_counter()
     for _ in range(solo_irs):
@@ -221,6 +223,8 @@ def main():
         host_hist.copy_(hist, non_blocking=True)
         torch.cuda.synchronize()
     to_host_latency_ms = (time.perf_counter() - t0) * 1e3 / solo_irs
+    for c in contexts:
+        c.set_concurrent_traces(pipeline.group_size(len(contexts)))
 
     pipeline.run(args.warmup, trace_args, ir_kwargs(None), keep)
     elapsed = timed(args.steps, ir_kwargs(kernel_ms))
@@ -273,7 +277,8 @@ def main():
     if rank == 0:
         avg = {k: float(np.mean(v)) for k, v in kernel_ms.items()}
         solo = {k: float(np.mean(v)) for k, v in solo_ms.items()}       # one IR alone on the GPU (untimed pass above)
-        trace_ms = sum(solo.get(k, 0.0) for k in ("path_kernel", "image_kernel", "shadow_kernel"))
+        # (the library names a timing after the kernel that ran: path_kernel / path_pair_kernel, shadow_kernel / shadow_pair_kernel)
+        trace_ms = sum(solo.get(k, 0.0) for k in ("path_kernel", "path_pair_kernel", "image_kernel", "shadow_kernel", "shadow_pair_kernel"))
         dominant = max(solo, key=solo.get)                              # by the time the kernel itself needs
         # Kernel durations for the rooflines come from the solo pass (HIP events around each launch with one IR on the GPU): in the
         # timed region the kernels of several IRs interleave and the events around a launch then span its neighbour's work as well.
@@ -310,7 +315,7 @@ def main():
         # per issued VALU instruction / 64 (SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU x 64)): masked-off lanes of the quad
         # kernels (a wave's 16 rays are not all in the step kind being executed) are issued but do nothing.
         valu = {}
-        for k in ("path_kernel", "shadow_kernel", "image_kernel"):
+        for k in ("path_kernel", "path_pair_kernel", "shadow_kernel", "shadow_pair_kernel", "image_kernel"):
             v = pmc.get(k, {})
             if "SQ_INSTS_VALU" in v and solo.get(k):
                 a = v["SQ_INSTS_VALU"] / (solo[k] * 1e-3) / 1e9
@@ -325,9 +330,10 @@ def main():
                 valu[k] = entry
         stream = {}
         algorithmic = {"shadow_kernel": 128.0 * nrays * nrefl,          # 64-byte work record read, 64-byte Impulse written
+                       "shadow_pair_kernel": 128.0 * nrays * nrefl,
                        "time_range_kernel": 64.0 * nrays * nrefl, "histogram_fast_kernel": 64.0 * nrays * nrefl,
                        "exact_mode": (64.0 + 8.0 + 64.0) * nrays * nrefl}   # keys pass, (key, index) pairs out, gather of the records
-        for k in ("shadow_kernel", "time_range_kernel", "histogram_fast_kernel", "exact_mode"):
+        for k in ("shadow_kernel", "shadow_pair_kernel", "time_range_kernel", "histogram_fast_kernel", "exact_mode"):
             if k in solo and solo[k] > 0:                # against the kernel's duration with the GPU to itself
                 a = algorithmic[k] / (solo[k] * 1e-3) / 1e9
                 stream[k] = {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,

@@ -87,6 +87,11 @@ int rvb_scene_info(rvb_ctx * ctx, uint64_t * nodes, uint64_t * kept_triangles, u
  * The device variant borrows the caller's buffer and does not inspect it: the same contract is the caller's to keep. */
 int rvb_set_directions(rvb_ctx * ctx, const rvb_float3 * directions, uint64_t nrays);          /* host */
 int rvb_set_directions_device(rvb_ctx * ctx, const void * d_directions, uint64_t nrays);        /* device, borrowed */
+/* A hint, never a change of results: how many traces of this size the caller keeps in flight on the device at a time (several
+ * contexts whose streams run side by side; default 1).  The path kernel spends two lanes per ray instead of four when the rays in
+ * flight fill the chip without the extra waves (csrc/trace_kernels.hip, rvb_path_lanes_for).  No reference counterpart: the
+ * reference runs one 4096-ray group at a time (rayverb.cpp:586-591). */
+int rvb_set_concurrent_traces(rvb_ctx * ctx, uint32_t traces);
 
 /* ---- trace: replaces Raytracer::raytrace (rayverb.cpp:538-685) + kernel raytrace
  * (kernel.cpp:304-503).  Traces exactly nrays rays (all at once, no 4096-ray groups) for

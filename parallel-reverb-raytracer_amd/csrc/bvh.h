@@ -32,7 +32,9 @@
 #define RVB_BVH_STACK 64            // per-lane traversal stack entries (LDS)
 
 struct BvhChild {                   // 16 B = one 16-byte load
-    uint16_t lox, loy, loz, hix, hiy, hiz;   // binary16 bit patterns
+    uint16_t lox, hix, loy, hiy, loz, hiz;   // binary16 bit patterns, the two planes of an axis in one 32-bit word (a conditional
+                                    // swap of its halves puts the plane the ray meets first in the low half: slab_select in
+                                    // trace_kernels.hip).  An EMPTY slot holds lo = +inf, hi = -inf.
     uint32_t ref;                   // EMPTY | LEAF|(count-1)<<28|first | node index << RVB_BVH_NODE_SHIFT
 };
 struct BvhNode { BvhChild c[4]; };  // 64 B

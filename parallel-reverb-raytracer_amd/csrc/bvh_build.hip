@@ -548,7 +548,8 @@ std::string rvb_build_scene(const rvb_triangle * triangles, uint64_t ntriangles,
         std::memset(&root, 0, sizeof(root));
         for (int c = 0; c < 4; ++c) {
             root.c[c].ref = RVB_BVH_EMPTY;
-            root.c[c].lox = root.c[c].loy = root.c[c].loz = root.c[c].hix = root.c[c].hiy = root.c[c].hiz = 0x7E00u;   // NaN
+            root.c[c].lox = root.c[c].loy = root.c[c].loz = 0x7C00u;      // +inf
+            root.c[c].hix = root.c[c].hiy = root.c[c].hiz = 0xFC00u;      // -inf
         }
         out.nodes.push_back(root);
         out.depth = 1;
@@ -622,8 +623,10 @@ std::string rvb_build_scene(const rvb_triangle * triangles, uint64_t ntriangles,
             BvhChild & slot = node.c[k];
             if (k >= nk) {
                 slot.ref = RVB_BVH_EMPTY;
-                // empty slot: rejected by its ref in the slab test; the box is never used
-                slot.lox = slot.loy = slot.loz = slot.hix = slot.hiy = slot.hiz = 0x7E00u;
+                // empty slot: an inverted box (lo = +inf, hi = -inf), which no ray enters in the plane-selecting slab test
+                // (slab_select: entry = +inf, exit = -inf); the min / max form (slab) sees all of space and rejects the slot by its ref
+                slot.lox = slot.loy = slot.loz = 0x7C00u;
+                slot.hix = slot.hiy = slot.hiz = 0xFC00u;
                 continue;
             }
             const BinNode & c = b.nodes[kids[k]];

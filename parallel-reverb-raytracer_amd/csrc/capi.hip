@@ -61,6 +61,7 @@ struct rvb_ctx {
     DevBuf directions_own;
     const float4 * directions = nullptr;
     uint64_t nrays = 0;
+    uint32_t concurrent_traces = 1;             // rvb_set_concurrent_traces
     bool traced = false;
     uint64_t nreflections = 0;
     float mic[3] = {0, 0, 0};
@@ -363,6 +364,14 @@ int rvb_set_directions_device(rvb_ctx * ctx, const void * d_directions, uint64_t
     return RVB_OK;
 }
 
+int rvb_set_concurrent_traces(rvb_ctx * ctx, uint32_t traces)
+{
+    if (!ctx) return RVB_ERR_INVALID;
+    if (traces == 0 || traces > (1u << 20)) return fail(ctx, RVB_ERR_INVALID, "rvb_set_concurrent_traces: 1 .. 2^20");
+    ctx->concurrent_traces = traces;
+    return RVB_OK;
+}
+
 static int trace_common(rvb_ctx * ctx, const float * mics, const float * sources, uint64_t npairs, uint64_t nreflections,
                         const float air_coefficient[8], uint64_t ray_offset)
 {
@@ -454,6 +463,7 @@ static int trace_common(rvb_ctx * ctx, const float * mics, const float * sources
     a.stack_entries = ctx->stack_need;
     a.lds_surfaces = rvb_lds_surfaces(ctx->stack_need, ctx->nsurfaces);
     a.scene_nodes = (uint32_t) ctx->nnodes;
+    a.path_lanes = rvb_path_lanes_for(nrays, ctx->concurrent_traces);
     a.ray_offset = ray_offset;
     for (int i = 0; i < 3; ++i) { a.mic[i] = mic[i]; a.source[i] = source[i]; ctx->mic[i] = mic[i]; }
     for (int i = 0; i < 8; ++i) a.air[i] = air_coefficient[i];
@@ -463,8 +473,15 @@ static int trace_common(rvb_ctx * ctx, const float * mics, const float * sources
     RVB_HIP(ctx, hipMemsetAsync(ctx->stamps.p, 0, 32 * sizeof(unsigned long long), ctx->stream));
     a.scene.stamps = ctx->stamps.as<unsigned long long>();
 
+    // diagnostic only (timing probes whose path kernel leaves records unwritten, -DRVB_PROBE_NO_STORES): start from invalid records
+    static const bool probe_zero = getenv("RVB_PROBE_ZERO_RECORDS") != nullptr;
+    if (probe_zero) {
+        RVB_HIP(ctx, hipMemsetAsync(ctx->impulses.p, 0, imp_bytes, ctx->stream));
+        if (a.sort_keys) RVB_HIP(ctx, hipMemsetAsync(ctx->sort_keys.p, 0xFF, nrecords * 4, ctx->stream));
+    }
+
     ctx->reset_timings();
-    ctx->begin_timing("path_kernel");
+    ctx->begin_timing(a.path_lanes == 2 ? "path_pair_kernel" : "path_kernel");
     rvb_launch_path(a, ctx->stream);
     ctx->end_timing();
     // image_kernel and the record grouping both depend on path_kernel only: the first (latency-bound) runs on the
@@ -491,7 +508,7 @@ static int trace_common(rvb_ctx * ctx, const float * mics, const float * sources
         ctx->end_timing();
     }
     RVB_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_done, 0));
-    ctx->begin_timing("shadow_kernel");
+    ctx->begin_timing(rvb_shadow_lanes() == 2 ? "shadow_pair_kernel" : "shadow_kernel");
     rvb_launch_shadow(a, ctx->stream);
     ctx->end_timing();
     RVB_HIP(ctx, hipGetLastError());

@@ -37,6 +37,7 @@ struct TraceArgs {
     uint32_t stack_entries;             // LDS traversal stack entries per lane (BuiltScene::stack_need)
     uint32_t lds_surfaces;              // surfaces staged in LDS behind the stack by the quad kernels (rvb_lds_surfaces), 0 = none
     uint32_t scene_nodes;               // number of BVH nodes (experiments that stage the top of the tree)
+    uint32_t path_lanes;                // lanes per ray in the path kernel: 4 (path_kernel) or 2 (path_pair_kernel), rvb_path_lanes_for
     // Several (source, microphone) pairs in ONE launch (rvb_trace_pairs): ray r belongs to pair r / rays_per_pair and uses
     // direction r % rays_per_pair; its records, early ids, candidates follow the global ray number.  npairs == 1: mic / source below.
     uint32_t npairs;
@@ -54,6 +55,9 @@ struct TraceArgs {
 void rvb_launch_path(const TraceArgs & a, hipStream_t s);
 // How many surfaces the quad kernels stage in LDS for this scene (all of them, or 0 when they would cost occupancy).
 uint32_t rvb_lds_surfaces(uint32_t stack_entries, uint64_t nsurfaces);
+// lanes per ray for a launch of `nrays` rays when the caller keeps `concurrent` such traces in flight on the device
+uint32_t rvb_path_lanes_for(uint64_t nrays, uint32_t concurrent);
+uint32_t rvb_shadow_lanes();        // lanes per record in the shadow kernel: 2 (shadow_pair_kernel) unless RVB_SHADOW_LANES=4
 // Phase C: one lane per (ray, bounce < 9): image-source validation (kernel.cpp:379-457) + slot 0.
 void rvb_launch_images(const TraceArgs & a, hipStream_t s);
 // Phase B: one lane per (ray, bounce): diffuse shadow ray to the microphone and the final

@@ -28,6 +28,9 @@
 #ifndef RVB_PATH_JOBS
 #define RVB_PATH_JOBS 2     // 2: majority-vote job loop (traverse_jobs_vote), 1: while-while job loop, 0: one query at a time
 #endif
+#ifndef RVB_PROBE_NO_STORES
+#define RVB_PROBE_NO_STORES 0
+#endif
 #ifndef RVB_SHADOW_JOBS
 #define RVB_SHADOW_JOBS 0
 #endif
@@ -143,10 +146,10 @@ __device__ __forceinline__ bool slab(const uint4 n, const float ix, const float 
                                      const float oix, const float oiy, const float oiz,
                                      const float limit, const float neg_cull, const uint32_t skip, float & tn)
 {
-    const half2_t h0 = as_half2(n.x), h1 = as_half2(n.y), h2 = as_half2(n.z);   // (lo.x, lo.y) (lo.z, hi.x) (hi.y, hi.z)
-    const float tx0 = fmaf((float) h0.x, ix, -oix), tx1 = fmaf((float) h1.y, ix, -oix);
-    const float ty0 = fmaf((float) h0.y, iy, -oiy), ty1 = fmaf((float) h2.x, iy, -oiy);
-    const float tz0 = fmaf((float) h1.x, iz, -oiz), tz1 = fmaf((float) h2.y, iz, -oiz);
+    const half2_t h0 = as_half2(n.x), h1 = as_half2(n.y), h2 = as_half2(n.z);   // (lo.x, hi.x) (lo.y, hi.y) (lo.z, hi.z)
+    const float tx0 = fmaf((float) h0.x, ix, -oix), tx1 = fmaf((float) h0.y, ix, -oix);
+    const float ty0 = fmaf((float) h1.x, iy, -oiy), ty1 = fmaf((float) h1.y, iy, -oiy);
+    const float tz0 = fmaf((float) h2.x, iz, -oiz), tz1 = fmaf((float) h2.y, iz, -oiz);
     // The two folds with loop-invariant operands are written as instructions: fmaxf / fminf would first canonicalise
     // `neg_cull` and `limit` (values from another basic block are not known to be quiet) — two more VALU operations per
     // node step.  Neither is ever NaN; v_max / v_min return the other operand for a NaN box plane like fmaxf / fminf.
@@ -156,6 +159,31 @@ __device__ __forceinline__ bool slab(const uint4 n, const float ix, const float 
     tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), zn);
     const float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), zf);
     return tn <= tf && n.w != RVB_BVH_EMPTY && n.w != skip;
+}
+
+// The same test with the near / far plane of each axis SELECTED by the sign of the direction instead of computed as min / max of
+// both products: one v_perm_b32 per axis swaps the halves of the (lo, hi) word when the ray runs towards -axis, after which the low
+// half is the plane the ray meets first.  3 selects + 2 three-operand min / max replace 6 two-operand min / max and the EMPTY compare
+// (an empty slot is an inverted infinite box: entry +inf, exit -inf).  The products are monotonic in the plane, so entry and exit
+// are bit-identical to slab()'s.  sel*: slab_selector(inverse direction), 3 more registers per query — used by the two-lane
+// kernels, whose register budget is not the 64 of the quad kernels.
+__device__ __forceinline__ uint32_t slab_selector(float inv) { return inv < 0.0f ? 0x01000302u : 0x03020100u; }
+__device__ __forceinline__ bool slab_select(const uint4 n, const float ix, const float iy, const float iz,
+                                            const float oix, const float oiy, const float oiz,
+                                            const uint32_t selx, const uint32_t sely, const uint32_t selz,
+                                            const float limit, const float neg_cull, const uint32_t skip, float & tn)
+{
+    const half2_t hx = as_half2(__builtin_amdgcn_perm(n.x, n.x, selx)), hy = as_half2(__builtin_amdgcn_perm(n.y, n.y, sely)),
+                  hz = as_half2(__builtin_amdgcn_perm(n.z, n.z, selz));      // (near, far) per axis
+    const float nx = fmaf((float) hx.x, ix, -oix), fx = fmaf((float) hx.y, ix, -oix);
+    const float ny = fmaf((float) hy.x, iy, -oiy), fy = fmaf((float) hy.y, iy, -oiy);
+    const float nz = fmaf((float) hz.x, iz, -oiz), fz = fmaf((float) hz.y, iz, -oiz);
+    float zn = nz, zf = fz;
+    asm("v_max_f32 %0, %1, %2" : "=v"(zn) : "s"(neg_cull), "v"(zn));      // (written as instructions: see slab)
+    asm("v_min_f32 %0, %1, %2" : "=v"(zf) : "v"(zf), "v"(limit));
+    tn = fmaxf(fmaxf(nx, ny), zn);
+    const float tf = fminf(fminf(fx, fy), zf);
+    return tn <= tf && n.w != skip;
 }
 
 // Closest hit (ANY = false): the brute-force winner of reference kernel.cpp:167-192.
@@ -457,6 +485,192 @@ __device__ __forceinline__ void traverse_jobs_vote(const SceneDev & sc, uint32_t
 #undef RVB_RESET_QUERY
 }
 
+// TWO LANES PER RAY (path_kernel at RVB_PATH_LANES = 2): a lane owns two children of a node and two triangles of a leaf, a wave
+// carries 32 rays.  The vote, the stack handling, the reductions and the loads' addressing are per-RAY work that every lane of
+// the ray repeats: with two lanes instead of four a node step costs ~1.45x the instructions for twice the rays.  (One lane per
+// ray would be cheaper still per ray, but 100 k rays are then 1.5 waves per SIMD, too few to cover a node fetch.)
+// stack: this pair's column of the LDS stack, entries PAIRS_PER_BLOCK words apart.
+#define PAIRS_PER_BLOCK 32
+#ifndef RVB_PAIR_SELECT
+#define RVB_PAIR_SELECT 1          // bit 0: path_pair_kernel, bit 1: shadow_pair_kernel use slab_select (near / far plane by the direction's sign)
+                                   // instead of slab (min / max).  Measured at C2: path pairs 3.92 -> 3.80 ms, shadow pairs 1.28 -> 1.34 ms
+#endif
+#define RVB_PAIR_SLAB(SEL, n, tn, skip) ((SEL) ? slab_select(n, ix, iy, iz, oix, oiy, oiz, selx, sely, selz, limit, neg_cull, skip, tn) \
+                                               : slab(n, ix, iy, iz, oix, oiy, oiz, limit, neg_cull, skip, tn))
+template <class Job>
+__device__ __forceinline__ void traverse_pairs_vote(const SceneDev & sc, uint32_t * __restrict__ stack, Job & job,
+                                                    lds_float4_ptr lds_nodes = nullptr)
+{
+    const uint32_t IDLE = 0xFFFFFFFEu;
+    const uint32_t h = threadIdx.x & 1u;
+    const uint32_t c0 = 2u * h, c1 = c0 + 1u;                              // the children this lane owns
+    const uint32_t bit0 = 1u << c0, bit1 = 2u << c0, lt0 = bit0 - 1u, lt1 = bit1 - 1u;
+    const char * node_base = reinterpret_cast<const char *>(sc.nodes);
+    const char * tri_base = reinterpret_cast<const char *>(sc.tris);
+    const uint32_t child_off = 32u * h;
+    const float neg_cull = -sc.cull_abs, cull_scale = 1.0f + sc.cull_rel;
+    const unsigned long long NO_HIT_KEY = (0x7F800000ull << 32) | NONE;
+    v3 o = mk3(0, 0, 0), d = mk3(0, 0, 0);
+    float tmax = 0.0f;
+    float ix = 0.0f, iy = 0.0f, iz = 0.0f, oix = 0.0f, oiy = 0.0f, oiz = 0.0f;
+    unsigned long long best_key = NO_HIT_KEY;
+    uint32_t sp = 0, ref = IDLE;
+    uint32_t selx = 0, sely = 0, selz = 0;
+#define RVB_RESET_QUERY()                                                         \
+    {                                                                             \
+        ix = clamp_inv(d.x); iy = clamp_inv(d.y); iz = clamp_inv(d.z);            \
+        oix = o.x * ix; oiy = o.y * iy; oiz = o.z * iz;                           \
+        selx = slab_selector(ix); sely = slab_selector(iy); selz = slab_selector(iz); \
+        best_key = NO_HIT_KEY; sp = 0; ref = 0;                                   \
+    }
+    if (job.next(o, d, tmax)) RVB_RESET_QUERY()
+    for (;;) {
+        const unsigned long long m_node = __builtin_amdgcn_ballot_w64((int32_t) ref >= 0);
+        const unsigned long long m_done = __builtin_amdgcn_ballot_w64(ref == NONE);
+        const unsigned long long m_leaf = __builtin_amdgcn_ballot_w64((int32_t) ref < (int32_t) IDLE);
+        const int n_node = scalar_popcount(m_node), n_done = scalar_popcount(m_done), n_leaf = scalar_popcount(m_leaf);
+        if ((n_node | n_done | n_leaf) == 0)
+            break;
+        if (n_node >= n_leaf && n_node >= n_done) {
+            if ((int32_t) ref >= 0) {
+#if RVB_LDS_NODES
+                uint4 n0, n1;
+                if (ref < RVB_LDS_NODES * 64u) {
+                    const nt_float4 t0 = lds_nodes[(ref | child_off) >> 4], t1 = lds_nodes[((ref | child_off) >> 4) + 1];
+                    n0 = make_uint4(__float_as_uint(t0.x), __float_as_uint(t0.y), __float_as_uint(t0.z), __float_as_uint(t0.w));
+                    n1 = make_uint4(__float_as_uint(t1.x), __float_as_uint(t1.y), __float_as_uint(t1.z), __float_as_uint(t1.w));
+                } else {
+                    const uint4 * np = reinterpret_cast<const uint4 *>(node_base + (ref | child_off));
+                    n0 = np[0]; n1 = np[1];
+                }
+#else
+                const uint4 * np = reinterpret_cast<const uint4 *>(node_base + (ref | child_off));
+                const uint4 n0 = np[0], n1 = np[1];
+#endif
+                const float limit = fmaf(__uint_as_float((uint32_t) (best_key >> 32)), cull_scale, sc.cull_abs);
+                float tn0, tn1;
+                const bool ok0 = RVB_PAIR_SLAB(RVB_PAIR_SELECT & 1, n0, tn0, job.skip_ref());
+                const bool ok1 = RVB_PAIR_SLAB(RVB_PAIR_SELECT & 1, n1, tn1, job.skip_ref());
+                const uint32_t key0 = ok0 ? ((__float_as_uint(fmaxf(tn0, 0.0f)) & ~3u) | c0) : NONE;
+                const uint32_t key1 = ok1 ? ((__float_as_uint(fmaxf(tn1, 0.0f)) & ~3u) | c1) : NONE;
+                uint32_t kmin = min(key0, key1);
+                kmin = min(kmin, dpp_u<QP_SWAP1>(kmin));
+                if (kmin == NONE) {
+                    if (sp > 0) { --sp; ref = stack[sp * PAIRS_PER_BLOCK]; } else ref = NONE;
+                } else {
+                    const uint32_t winner = kmin & 3u;
+                    uint32_t okmask = (ok0 ? bit0 : 0u) | (ok1 ? bit1 : 0u);
+                    okmask |= dpp_u<QP_SWAP1>(okmask);
+                    const uint32_t rest = okmask & ~(1u << winner);
+                    if (ok0 && c0 != winner)
+                        stack[(sp + __popc(rest & lt0)) * PAIRS_PER_BLOCK] = n0.w;
+                    if (ok1 && c1 != winner)
+                        stack[(sp + __popc(rest & lt1)) * PAIRS_PER_BLOCK] = n1.w;
+                    sp += __popc(rest);
+                    const uint32_t mine = (winner & 1u) ? n1.w : n0.w;
+                    const uint32_t theirs = dpp_u<QP_SWAP1>(mine);
+                    ref = (winner >> 1) == h ? mine : theirs;
+                }
+            }
+        } else if (n_leaf >= n_done) {
+            if ((int32_t) ref < (int32_t) IDLE) {
+                // triangles h and h + 2 of the leaf (a two-triangle leaf gives each lane one)
+                const uint32_t first = ref & 0x0FFFFFFFu;
+                const uint32_t count = ((ref >> 28) & 7u) + 1u;
+                const uint32_t j0 = h, j1 = h + 2u;
+                const float4 * tp0 = reinterpret_cast<const float4 *>(tri_base + tri_byte_offset(first + (j0 < count ? j0 : 0u)));
+                const float4 * tp1 = reinterpret_cast<const float4 *>(tri_base + tri_byte_offset(first + (j1 < count ? j1 : 0u)));
+                float4 ta = tp0[0], tb = tp0[1], tc = tp0[2], ua = tp1[0], ub = tp1[1], uc = tp1[2];
+                asm volatile("" : "+v"(ta.x), "+v"(tb.x), "+v"(tc.x), "+v"(ua.x), "+v"(ub.x), "+v"(uc.x));   // all six loads leave before the first use
+                const float dist0 = mt_intersect(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), o, d);
+                const float dist1 = mt_intersect(mk3(ua.x, ua.y, ua.z), mk3(ua.w, ub.x, ub.y), mk3(ub.z, ub.w, uc.x), o, d);
+                // kernel.cpp:180-188 — smallest distance wins, equal distances go to the lower index: one unsigned 64-bit key
+                const bool valid0 = j0 < count && dist0 > RVB_EPSILON, valid1 = j1 < count && dist1 > RVB_EPSILON;
+                const unsigned long long k0 = valid0 ? (((unsigned long long) __float_as_uint(dist0) << 32) | __float_as_uint(tc.y)) : NO_HIT_KEY;
+                const unsigned long long k1 = valid1 ? (((unsigned long long) __float_as_uint(dist1) << 32) | __float_as_uint(uc.y)) : NO_HIT_KEY;
+                unsigned long long key = min_u64(k0, k1);
+                key = min_u64(key, dpp_u64<QP_SWAP1>(key));
+                best_key = min_u64(best_key, key);
+                if (sp > 0) { --sp; ref = stack[sp * PAIRS_PER_BLOCK]; } else ref = NONE;
+            }
+        } else {
+            if (ref == NONE) {
+                Hit hit;
+                hit.t = __uint_as_float((uint32_t) (best_key >> 32));
+                hit.tri = (uint32_t) best_key;
+                job.done(hit.tri != NONE, hit);
+                ref = IDLE;
+                if (job.next(o, d, tmax)) RVB_RESET_QUERY()
+            }
+        }
+    }
+#undef RVB_RESET_QUERY
+}
+
+// Any-hit query with two lanes per ray (shadow_pair_kernel): is there a triangle with EPSILON < distance <= tmax (the negation of
+// reference kernel.cpp:295).  Lockstep like traverse_quad<true>: the 32 pairs of the wave start a query together and leave the
+// loops as they finish; no visiting order (the lowest hit child is entered, the others pushed).
+#define QP_PAIR_LO 0xA0   // quad_perm [0,0,2,2]: both lanes of a pair read its even lane
+#define QP_PAIR_HI 0xF5   // quad_perm [1,1,3,3]: ... its odd lane
+__device__ __forceinline__ bool traverse_pair_any(const SceneDev & sc, const v3 o, const v3 d, const float tmax,
+                                                  uint32_t * __restrict__ stack, const uint32_t skip)
+{
+    const uint32_t h = threadIdx.x & 1u;
+    const uint32_t c0 = 2u * h;
+    const uint32_t bit0 = 1u << c0, bit1 = 2u << c0, lt0 = bit0 - 1u, lt1 = bit1 - 1u;
+    const char * node_base = reinterpret_cast<const char *>(sc.nodes);
+    const char * tri_base = reinterpret_cast<const char *>(sc.tris);
+    const uint32_t child_off = 32u * h;
+    const float neg_cull = -sc.cull_abs;
+    const float limit = fmaf(tmax, 1.0f + sc.cull_rel, sc.cull_abs);
+    const float ix = clamp_inv(d.x), iy = clamp_inv(d.y), iz = clamp_inv(d.z);
+    const float oix = o.x * ix, oiy = o.y * iy, oiz = o.z * iz;
+    const uint32_t selx = slab_selector(ix), sely = slab_selector(iy), selz = slab_selector(iz);
+    uint32_t sp = 0, ref = 0;
+    for (;;) {
+        while (!(ref & RVB_BVH_LEAF)) {
+            const uint4 * np = reinterpret_cast<const uint4 *>(node_base + (ref | child_off));
+            const uint4 n0 = np[0], n1 = np[1];
+            float tn0, tn1;
+            const bool ok0 = RVB_PAIR_SLAB(RVB_PAIR_SELECT & 2, n0, tn0, skip);
+            const bool ok1 = RVB_PAIR_SLAB(RVB_PAIR_SELECT & 2, n1, tn1, skip);
+            uint32_t okmask = (ok0 ? bit0 : 0u) | (ok1 ? bit1 : 0u);
+            okmask |= dpp_u<QP_SWAP1>(okmask);
+            if (okmask == 0u) {
+                if (sp > 0) { --sp; ref = stack[sp * PAIRS_PER_BLOCK]; } else ref = NONE;
+                continue;
+            }
+            const uint32_t rest = okmask & (okmask - 1u);             // all hit children but the lowest
+            const uint32_t winner_bit = okmask ^ rest;
+            if (ok0 && bit0 != winner_bit)
+                stack[(sp + __popc(rest & lt0)) * PAIRS_PER_BLOCK] = n0.w;
+            if (ok1 && bit1 != winner_bit)
+                stack[(sp + __popc(rest & lt1)) * PAIRS_PER_BLOCK] = n1.w;
+            sp += __popc(rest);
+            const uint32_t mine = (winner_bit & 0xAu) ? n1.w : n0.w;  // children 1, 3 are the lanes' second child
+            const uint32_t theirs = dpp_u<QP_SWAP1>(mine);
+            ref = (winner_bit & (bit0 | bit1)) ? mine : theirs;
+        }
+        if (ref == NONE)
+            return false;
+        // triangles h and h + 2 of the leaf
+        const uint32_t first = ref & 0x0FFFFFFFu;
+        const uint32_t count = ((ref >> 28) & 7u) + 1u;
+        const uint32_t j0 = h, j1 = h + 2u;
+        const float4 * tp0 = reinterpret_cast<const float4 *>(tri_base + tri_byte_offset(first + (j0 < count ? j0 : 0u)));
+        const float4 * tp1 = reinterpret_cast<const float4 *>(tri_base + tri_byte_offset(first + (j1 < count ? j1 : 0u)));
+        float4 ta = tp0[0], tb = tp0[1], tc = tp0[2], ua = tp1[0], ub = tp1[1], uc = tp1[2];
+        asm volatile("" : "+v"(ta.x), "+v"(tb.x), "+v"(tc.x), "+v"(ua.x), "+v"(ub.x), "+v"(uc.x));
+        const float dist0 = mt_intersect(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), o, d);
+        const float dist1 = mt_intersect(mk3(ua.x, ua.y, ua.z), mk3(ua.w, ub.x, ub.y), mk3(ub.z, ub.w, uc.x), o, d);
+        uint32_t hit = ((j0 < count && dist0 > RVB_EPSILON && dist0 <= tmax) || (j1 < count && dist1 > RVB_EPSILON && dist1 <= tmax)) ? 1u : 0u;
+        hit |= dpp_u<QP_SWAP1>(hit);
+        if (hit)
+            return true;
+        if (sp > 0) { --sp; ref = stack[sp * PAIRS_PER_BLOCK]; } else return false;
+    }
+}
+
 // A single query through the same loop (the quad's lanes return together).
 struct OneShotJob {
     v3 o, d;
@@ -585,7 +799,8 @@ __device__ __forceinline__ lds_float4_ptr stage_surfaces(const TraceArgs & a, ui
     return (lds_float4_ptr) dst;
 }
 
-template <bool SURF_LDS>
+// LANES = 4: quad lane c stores chunk c.  LANES = 2: lane c of the pair stores chunks c and c + 2.
+template <bool SURF_LDS, int LANES = 4>
 struct PathJob {
     const TraceArgs & a;
     uint32_t ray;                        // < 2^32 / 9 (rvb_trace checks)
@@ -637,18 +852,29 @@ struct PathJob {
         const float threshold = unit ? fmaf(sk.z, h.t, sk.y) : __builtin_inff();
         skip = diff > threshold ? __float_as_uint(sk.x) : RVB_BVH_EMPTY;
         float4 chunk = vol;
-        if (c == 2) chunk = make_float4(p.x, p.y, p.z, diff);
-        else if (c == 3) chunk = make_float4(new_dist, threshold, __uint_as_float(h.tri), __uint_as_float(pair_tag));   // tag: pair + 1, non-zero = valid
+        const float4 tail = make_float4(new_dist, threshold, __uint_as_float(h.tri), __uint_as_float(pair_tag));   // tag: pair + 1, non-zero = valid
+        if (LANES == 4) {
+            if (c == 2) chunk = make_float4(p.x, p.y, p.z, diff);
+            else if (c == 3) chunk = tail;
+        }
         // (the product is formed here, one v_mad_u64_u32 per bounce: hoisted out of the loop it would hold two more VGPRs for
         // the whole traversal, which at the 64-register budget of 8 waves per SIMD means a spill)
         uint32_t ray_here = ray;
         asm volatile("" : "+v"(ray_here));
         const uint64_t record = (uint64_t) ray_here * a.nreflections + index;
+#if RVB_PROBE_NO_STORES          // diagnostic build (wrong output): what the record stores cost the bounce chain
+        if (new_dist == 1.2345f) {
+#endif
         store_stream(reinterpret_cast<float4 *>(a.impulses + record) + c, chunk);
+        if (LANES == 2)
+            store_stream(reinterpret_cast<float4 *>(a.impulses + record) + c + 2, c == 0 ? make_float4(p.x, p.y, p.z, diff) : tail);
         if (c == 0 && index < RVB_NUM_IMAGE_SOURCE - 1)
             a.early[ray * (RVB_NUM_IMAGE_SOURCE - 1) + index] = h.tri;
         if (c == 1 && a.sort_keys)
             a.sort_keys[record] = a.scene.leafpos[h.tri];
+#if RVB_PROBE_NO_STORES
+        }
+#endif
         d = reflect3(normal, d);                                     // kernel.cpp:492-499
         o = p;
         distance = new_dist;
@@ -672,7 +898,7 @@ __global__ __launch_bounds__(WAVE, 8) void path_kernel(TraceArgs a)
         const uint4 * src = reinterpret_cast<const uint4 *>(a.scene.nodes);
         const uint32_t count = 4u * (RVB_LDS_NODES < a.scene_nodes ? RVB_LDS_NODES : a.scene_nodes);
         for (uint32_t i = threadIdx.x; i < 4u * RVB_LDS_NODES; i += WAVE)
-            dst[i] = i < count ? src[i] : make_uint4(0x7E007E00u, 0x7E007E00u, 0x7E007E00u, RVB_BVH_EMPTY);
+            dst[i] = i < count ? src[i] : make_uint4(0xFC007C00u, 0xFC007C00u, 0xFC007C00u, RVB_BVH_EMPTY);
         __syncthreads();
         lds_nodes = (lds_float4_ptr) dst;
     }
@@ -713,6 +939,59 @@ __global__ __launch_bounds__(WAVE, 8) void path_kernel(TraceArgs a)
     for (uint32_t i = job.index; i < a.nreflections; ++i) {
         const uint64_t record = ray * a.nreflections + i;
         store_stream(reinterpret_cast<float4 *>(a.impulses + record) + job.c, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+        if (job.c == 1 && a.sort_keys)
+            a.sort_keys[record] = NONE;
+    }
+    if (job.c == 0)
+        atomicAdd(a.executed, (unsigned long long) job.index);
+}
+
+// path_kernel with two lanes per ray (traverse_pairs_vote): 32 rays per single-wave workgroup.
+#ifndef RVB_PAIR_WAVES
+#define RVB_PAIR_WAVES 4            // waves per SIMD the register budget allows (100 k rays are 3.05 waves per SIMD)
+#endif
+template <bool SURF_LDS>
+__global__ __launch_bounds__(WAVE, RVB_PAIR_WAVES) void path_pair_kernel(TraceArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t stack_lds[];   // [stack_entries][PAIRS_PER_BLOCK]
+    const uint32_t q = threadIdx.x >> 1;
+    const uint64_t ray = (uint64_t) blockIdx.x * PAIRS_PER_BLOCK + q;
+    const lds_float4_ptr surf_lds = stage_surfaces(a, stack_lds + a.stack_entries * PAIRS_PER_BLOCK);
+#if RVB_LDS_NODES
+    lds_float4_ptr lds_nodes;
+    {
+        uint4 * dst = reinterpret_cast<uint4 *>(stack_lds + a.stack_entries * PAIRS_PER_BLOCK) + 4u * a.lds_surfaces;
+        const uint4 * src = reinterpret_cast<const uint4 *>(a.scene.nodes);
+        const uint32_t count = 4u * (RVB_LDS_NODES < a.scene_nodes ? RVB_LDS_NODES : a.scene_nodes);
+        for (uint32_t i = threadIdx.x; i < 4u * RVB_LDS_NODES; i += WAVE)
+            dst[i] = i < count ? src[i] : make_uint4(0xFC007C00u, 0xFC007C00u, 0xFC007C00u, RVB_BVH_EMPTY);
+        __syncthreads();
+        lds_nodes = (lds_float4_ptr) dst;
+    }
+#endif
+    if (ray >= a.nrays)
+        return;                                   // whole pairs leave together
+    uint32_t pair = 0, local = (uint32_t) ray;
+    v3 source = ld3(a.source);
+    if (a.npairs > 1) {
+        pair = (uint32_t) ray / a.rays_per_pair;
+        local = (uint32_t) ray - pair * a.rays_per_pair;
+        const float4 s4 = a.pair_sources[pair];
+        source = mk3(s4.x, s4.y, s4.z);
+    }
+    const float4 d4 = a.directions[local];
+    const float len2 = d4.x * d4.x + d4.y * d4.y + d4.z * d4.z;
+    PathJob<SURF_LDS, 2> job = {a, (uint32_t) ray, threadIdx.x & 1u, source, mk3(d4.x, d4.y, d4.z), 0.0f,
+                   make_float4(1.0f, 1.0f, 1.0f, 1.0f), 0u, true, surf_lds, pair + 1u, RVB_BVH_EMPTY, fabsf(len2 - 1.0f) < 1e-3f};
+#if RVB_LDS_NODES
+    traverse_pairs_vote(a.scene, stack_lds + q, job, lds_nodes);
+#else
+    traverse_pairs_vote(a.scene, stack_lds + q, job);
+#endif
+    for (uint32_t i = job.index; i < a.nreflections; ++i) {       // an escaped ray's remaining slots (as in path_kernel)
+        const uint64_t record = ray * a.nreflections + i;
+        store_stream(reinterpret_cast<float4 *>(a.impulses + record) + job.c, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+        store_stream(reinterpret_cast<float4 *>(a.impulses + record) + job.c + 2, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
         if (job.c == 1 && a.sort_keys)
             a.sort_keys[record] = NONE;
     }
@@ -987,6 +1266,9 @@ struct ShadowJob {
     }
 };
 
+#ifndef RVB_SHADOW_PAIR_WAVES
+#define RVB_SHADOW_PAIR_WAVES 5
+#endif
 #ifndef RVB_SHADOW_WAVES
 #define RVB_SHADOW_WAVES 8     // 64 VGPRs (8 waves/SIMD): 1.845 -> 1.807 ms against 7
 #endif
@@ -1033,6 +1315,86 @@ __global__ __launch_bounds__(WAVE, RVB_SHADOW_WAVES) void shadow_kernel(TraceArg
     }
 }
 
+// shadow_kernel with two lanes per record: lane 0 carries chunks 0 and 2 of the 64-byte record (bands 0-3; hit point, DIFF), lane 1
+// chunks 1 and 3 (bands 4-7; distance, own-plane threshold, triangle, tag).  Each lane evaluates the four attenuations of its bands.
+template <bool SURF_LDS>
+__global__ __launch_bounds__(WAVE, RVB_SHADOW_PAIR_WAVES) void shadow_pair_kernel(TraceArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t stack_lds[];   // [stack_entries][PAIRS_PER_BLOCK]
+    const uint32_t h = threadIdx.x & 1u;
+    const uint32_t q = threadIdx.x >> 1;
+    uint32_t * stack = stack_lds + q;
+    const lds_float4_ptr surf_lds = stage_surfaces(a, stack_lds + a.stack_entries * PAIRS_PER_BLOCK);
+    const uint64_t stride = (uint64_t) gridDim.x * PAIRS_PER_BLOCK, total = a.nrays * (uint64_t) a.nreflections;
+    v3 mic = ld3(a.mic);
+    const float air0 = a.air[4 * h], air1 = a.air[4 * h + 1], air2 = a.air[4 * h + 2], air3 = a.air[4 * h + 3];
+    float tmin = __builtin_inff(), tmax_seen = 0.0f;
+    for (uint64_t g = (uint64_t) blockIdx.x * PAIRS_PER_BLOCK + q; g < total; g += stride) {
+        float4 * rec = reinterpret_cast<float4 *>(a.impulses + (a.sort_order ? (uint64_t) a.sort_order[g] : g));
+        const float4 vol = load_stream(rec + h), aux = load_stream(rec + h + 2);
+        const uint32_t tag = dpp_u<QP_PAIR_HI>(__float_as_uint(aux.w));
+        if (tag == 0u)
+            continue;                             // ray had already escaped: slot keeps its zero fill
+        uint32_t pair = 0;
+        if (a.npairs > 1) {
+            const float4 m4 = a.pair_mics[tag - 1u];
+            mic = mk3(m4.x, m4.y, m4.z);
+            pair = tag - 1u;
+        }
+        const float new_dist = dpp_f<QP_PAIR_HI>(aux.x), threshold = dpp_f<QP_PAIR_HI>(aux.y);
+        const float4 * shade = reinterpret_cast<const float4 *>(a.scene.shade + dpp_u<QP_PAIR_HI>(__float_as_uint(aux.z)));
+        const float4 sh = shade[0];
+        const uint32_t skip_ref = __float_as_uint(shade[1].x);
+        const uint32_t surface = __float_as_uint(sh.w);
+        const v3 p = mk3(dpp_f<QP_PAIR_LO>(aux.x), dpp_f<QP_PAIR_LO>(aux.y), dpp_f<QP_PAIR_LO>(aux.z));
+        const float diff = dpp_f<QP_PAIR_LO>(aux.w);
+        const v3 b2p = mic - p;                   // kernel.cpp:282-286
+        const float mag = length3(b2p);
+        const v3 dir = normalize3(b2p);
+        const uint32_t skip = fabsf(dot3(mk3(sh.x, sh.y, sh.z), dir)) > threshold ? skip_ref : RVB_BVH_EMPTY;
+        const bool visible = !traverse_pair_any(a.scene, p, dir, mag, stack, skip);
+        const float dist = visible ? new_dist + mag : 0.0f;          // kernel.cpp:471
+        float4 o = make_float4(0, 0, 0, 0);
+        if (visible) {
+            float4 dc;                                               // diffuse coefficients of this lane's four bands
+            if (SURF_LDS) dc = lds_load4(surf_lds, 4 * surface + 2 + h);
+            else dc = reinterpret_cast<const float4 *>(a.scene.surfaces + surface)[2 + h];
+            // kernel.cpp:480-485: newVol * attenuation * diffuse * DIFF, left to right
+            o.x = ((vol.x * (air_attenuation(dist, air0) * 1.0f)) * dc.x) * diff;
+            o.y = ((vol.y * (air_attenuation(dist, air1) * 1.0f)) * dc.y) * diff;
+            o.z = ((vol.z * (air_attenuation(dist, air2) * 1.0f)) * dc.z) * diff;
+            o.w = ((vol.w * (air_attenuation(dist, air3) * 1.0f)) * dc.w) * diff;
+        }
+        const float t = seconds_per_meter() * dist;                  // kernel.cpp:489
+        store_stream(rec + h, o);
+        store_stream(rec + h + 2, h == 0 ? make_float4(p.x, p.y, p.z, 0.0f) : make_float4(t, 0.0f, 0.0f, 0.0f));
+        // inputs of findPredelay / MAX_SAMPLE (rayverb.h:49-74, rayverb.cpp:54-57): an impulse takes part iff any band is non-zero
+        uint32_t nonzero = (o.x != 0.0f || o.y != 0.0f || o.z != 0.0f || o.w != 0.0f) ? 1u : 0u;
+        nonzero |= dpp_u<QP_SWAP1>(nonzero);
+        if (nonzero) {
+            if (a.npairs > 1) {
+                if (h == 0) {
+                    const volatile uint32_t * seen = a.time_range + 2u * pair;
+                    if (t != 0.0f && __float_as_uint(t) < seen[0]) atomicMin(a.time_range + 2u * pair, __float_as_uint(t));
+                    if (__float_as_uint(t) > seen[1]) atomicMax(a.time_range + 2u * pair + 1u, __float_as_uint(t));
+                }
+            } else {
+                if (t != 0.0f) tmin = fminf(tmin, t);
+                tmax_seen = fmaxf(tmax_seen, t);
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        tmin = fminf(tmin, __shfl_xor(tmin, off));
+        tmax_seen = fmaxf(tmax_seen, __shfl_xor(tmax_seen, off));
+    }
+    if (threadIdx.x == 0 && a.npairs <= 1) {
+        const volatile uint32_t * seen = a.time_range;
+        if (tmin != __builtin_inff() && __float_as_uint(tmin) < seen[0]) atomicMin(a.time_range + 0, __float_as_uint(tmin));
+        if (__float_as_uint(tmax_seen) > seen[1]) atomicMax(a.time_range + 1, __float_as_uint(tmax_seen));
+    }
+}
+
 }  // namespace
 
 // LDS of a quad kernel's single-wave workgroup: the traversal stack, then (optionally) the surface table
@@ -1047,14 +1409,36 @@ uint32_t rvb_lds_surfaces(uint32_t stack_entries, uint64_t nsurfaces)
     static const bool off = getenv("RVB_LDS_SURFACES") && getenv("RVB_LDS_SURFACES")[0] == '0';
     const size_t budget = (160u * 1024u) / 32u;
     const size_t stack = (size_t) stack_entries * QUADS_PER_BLOCK * sizeof(uint32_t);
-    if (off || nsurfaces == 0 || stack + nsurfaces * sizeof(rvb_surface) > budget)
+    // ... and the two-lane kernels (twice the stack per workgroup) want 5 waves/SIMD = 20 workgroups per CU
+    const size_t pair_budget = (160u * 1024u) / 20u;
+    const size_t pair_stack = (size_t) stack_entries * PAIRS_PER_BLOCK * sizeof(uint32_t);
+    if (off || nsurfaces == 0 || stack + nsurfaces * sizeof(rvb_surface) > budget || pair_stack + nsurfaces * sizeof(rvb_surface) > pair_budget)
         return 0;
     return (uint32_t) nsurfaces;
+}
+
+// Lanes per ray of the path kernel.  Per ray-bounce the pair kernel issues 17 % fewer VALU instructions than the quad kernel (the
+// vote, stack and reduction work is per ray and every lane of the ray repeats it), but it has half the waves: it pays when the rays
+// in flight fill the chip without the extra waves — one resident round of pair waves at 6 waves per SIMD is 6 x 1024 x 32 rays.
+// Measured at workload C2 sizes (path kernel alone, ms per 100 k rays, quads / pairs): 100 k rays 3.60 / 3.79, 200 k 3.12 / 3.13,
+// 400 k 2.77 / 2.49, 1 M 2.51 / 2.16; two 100 k traces in flight (the bench pipeline): 5.32 / 5.11 ms per IR.
+uint32_t rvb_path_lanes_for(uint64_t nrays, uint32_t concurrent)
+{
+    static const int forced = getenv("RVB_PATH_LANES") ? atoi(getenv("RVB_PATH_LANES")) : 0;     // diagnostic override
+    if (forced == 2 || forced == 4) return (uint32_t) forced;
+    return nrays * (concurrent ? concurrent : 1u) >= 6ull * 1024ull * PAIRS_PER_BLOCK ? 2u : 4u;
 }
 
 void rvb_launch_path(const TraceArgs & a, hipStream_t s)
 {
     if (a.nrays == 0) return;
+    if (a.path_lanes == 2) {
+        const unsigned blocks = (unsigned) ((a.nrays + PAIRS_PER_BLOCK - 1) / PAIRS_PER_BLOCK);
+        const size_t lds = a.stack_entries * PAIRS_PER_BLOCK * sizeof(uint32_t) + (size_t) a.lds_surfaces * sizeof(rvb_surface) + RVB_LDS_NODES * 64u;
+        if (a.lds_surfaces) hipLaunchKernelGGL(path_pair_kernel<true>, dim3(blocks), dim3(WAVE), lds, s, a);
+        else hipLaunchKernelGGL(path_pair_kernel<false>, dim3(blocks), dim3(WAVE), lds, s, a);
+        return;
+    }
     const unsigned blocks = (unsigned) ((a.nrays + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK);
     if (a.lds_surfaces) hipLaunchKernelGGL(path_kernel<true>, dim3(blocks), dim3(WAVE), quad_kernel_lds_bytes(a), s, a);
     else hipLaunchKernelGGL(path_kernel<false>, dim3(blocks), dim3(WAVE), quad_kernel_lds_bytes(a), s, a);
@@ -1066,6 +1450,14 @@ void rvb_launch_images(const TraceArgs & a, hipStream_t s)
     hipLaunchKernelGGL(image_kernel, dim3(blocks ? blocks : 1), dim3(WAVE), a.stack_entries * WAVE * sizeof(uint32_t), s, a);
 }
 
+// Two lanes per record by default (shadow_pair_kernel): 12.8 M records fill the chip whatever the lane count, and a record costs
+// 12 % less (C2: 1.45 -> 1.28 ms).  RVB_SHADOW_LANES=4 keeps the quad kernel (measurements).
+uint32_t rvb_shadow_lanes()
+{
+    static const int lanes = getenv("RVB_SHADOW_LANES") ? atoi(getenv("RVB_SHADOW_LANES")) : 2;
+    return lanes == 4 ? 4u : 2u;
+}
+
 void rvb_launch_shadow(const TraceArgs & a, hipStream_t s)
 {
     const uint64_t total = a.nrays * (uint64_t) a.nreflections;
@@ -1073,6 +1465,15 @@ void rvb_launch_shadow(const TraceArgs & a, hipStream_t s)
     uint64_t blocks = (total + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK;
     static const uint64_t per_cu = getenv("RVB_SHADOW_WG_PER_CU") ? strtoull(getenv("RVB_SHADOW_WG_PER_CU"), nullptr, 10) : 256;
     if (blocks > 256u * per_cu) blocks = 256u * per_cu;     // single-wave workgroups per CU; records beyond are grid-strided
+    if (rvb_shadow_lanes() == 2) {
+        blocks = (total + PAIRS_PER_BLOCK - 1) / PAIRS_PER_BLOCK;
+        static const uint64_t pair_per_cu = getenv("RVB_SHADOW_WG_PER_CU") ? strtoull(getenv("RVB_SHADOW_WG_PER_CU"), nullptr, 10) : 256;
+        if (blocks > 256u * pair_per_cu) blocks = 256u * pair_per_cu;
+        const size_t lds = a.stack_entries * PAIRS_PER_BLOCK * sizeof(uint32_t) + (size_t) a.lds_surfaces * sizeof(rvb_surface);
+        if (a.lds_surfaces) hipLaunchKernelGGL(shadow_pair_kernel<true>, dim3((unsigned) blocks), dim3(WAVE), lds, s, a);
+        else hipLaunchKernelGGL(shadow_pair_kernel<false>, dim3((unsigned) blocks), dim3(WAVE), lds, s, a);
+        return;
+    }
     if (a.lds_surfaces) hipLaunchKernelGGL(shadow_kernel<true>, dim3((unsigned) blocks), dim3(WAVE), quad_kernel_lds_bytes(a), s, a);
     else hipLaunchKernelGGL(shadow_kernel<false>, dim3((unsigned) blocks), dim3(WAVE), quad_kernel_lds_bytes(a), s, a);
 }

@@ -186,6 +186,15 @@ class IrPipeline:
         self.tracers = list(tracers)
         self.next_slot = 0
         self.begun = [False] * len(self.tracers)
+        # the traces of a group run side by side (run_jobs): tell the contexts, so that the path kernel is sized for the rays in flight
+        for t in self.tracers:
+            if hasattr(t, "set_concurrent_traces"):
+                t.set_concurrent_traces(self.group_size(len(self.tracers)))
+
+    @staticmethod
+    def group_size(n):
+        group = max(1, n // 2) if n > 1 else 1
+        return min(group, int(__import__("os").environ.get("RVB_PIPELINE_GROUP", group)))       # (an override may only shrink it)
 
     def run(self, count, trace_args, ir_kwargs, on_result=None):
         """`count` IRs with the same arguments (bench) — trace_args = (mic, source, nreflections, air), ir_kwargs as
@@ -210,8 +219,7 @@ class IrPipeline:
         # per SIMD, see DESIGN.md "rays per launch"), and group j+1 is enqueued before group j is finished.  group =
         # len(tracers) // 2; two contexts: group 1 = the plain alternation.  RVB_PIPELINE_AHEAD=k instead keeps k traces
         # enqueued ahead of the IR being finished (k < len(tracers)).
-        group = max(1, n // 2) if n > 1 else 1
-        group = min(group, int(__import__("os").environ.get("RVB_PIPELINE_GROUP", group)))       # (an override may only shrink it)
+        group = self.group_size(n)
         ahead = min(n - 1, int(__import__("os").environ.get("RVB_PIPELINE_AHEAD", 0)))
         begun_upto = [0]                                     # jobs [0, begun_upto) have been begun
 

@@ -185,8 +185,18 @@ def check_every_ray_against_gpu_brute_force(ctx, oracle, gpu_oracle, scene, mic,
     assert np.array_equal(cands["index"], idx[rays[order], slots[order] + 1].astype(np.uint32))
     img = image.reshape(nrays, 10)[rays[order], slots[order] + 1]
     assert np.array_equal(cands["impulse"]["position"][:, :3], img["position"][:, :3]) and np.array_equal(cands["impulse"]["time"], img["time"])
+    # the other path kernel (two lanes per ray instead of four, or the reverse): the same bytes
+    first_lanes = 2 if nrays >= 196608 else 4
+    ctx.set_concurrent_traces(1 << 20 if first_lanes == 4 else 1)
+    try:
+        ctx.raytrace(mic, src, dirs, nrefl, AIR_COEFFICIENTS)
+        again = ctx.get_raw_diffuse()
+        assert again.tobytes() == got.tobytes(), "the two-lane and four-lane path kernels disagree"
+        assert ctx.get_image_candidates().tobytes() == cands.tobytes()
+    finally:
+        ctx.set_concurrent_traces(1)
     return {"rays": int(nrays), "impulses": int(got.shape[0]), "volume_values_off_by_one_ulp": int((ulps == 1).sum()),
-            "image_source_slots": int(rays.shape[0])}
+            "image_source_slots": int(rays.shape[0]), "both_path_kernels": True}
 
 
 def test_c2_every_ray_of_the_full_run_against_brute_force_on_the_gpu(ctx, oracle, gpu_oracle):

@@ -20,10 +20,14 @@ pytestmark = pytest.mark.gpu
 TRACE_CASES = ["trace_large_square", "trace_echo_tunnel", "trace_random_pillars", "trace_vault"]
 
 
-@pytest.fixture(scope="module")
-def ctx():
+@pytest.fixture(scope="module", params=["four_lanes_per_ray", "two_lanes_per_ray"])
+def ctx(request):
+    """Every test of this module runs with both path kernels: the quad kernel (what a small launch gets) and the pair kernel
+    (forced here by announcing many concurrent traces, rvb_set_concurrent_traces)."""
     from parallel_reverb_raytracer_amd import capi
     c = capi.Context(0)          # raises when librvb_hip.so or the GPU is missing: no fallback
+    if request.param == "two_lanes_per_ray":
+        c.set_concurrent_traces(1 << 20)
     yield c
     c.close()
 
@@ -99,6 +103,31 @@ def test_trace_matches_oracle_on_seeded_scenes(ctx, oracle, name, make, nrays, n
         assert_impulses_equal(ctx.get_raw_images(remove_direct), oracle.collect_images(image, index, remove_direct), name + " images")
     executed = int(np.count_nonzero(want["position"][:, :3].any(axis=1) | (want["time"] != 0) | want["volume"].any(axis=1)))
     assert ctx.executed_bounces() >= executed
+
+
+def test_quad_shadow_kernel_gives_the_same_bytes(ctx):
+    """The shadow kernel runs two lanes per record; the four-lane kernel it replaced stays in the library for measurements
+    (RVB_SHADOW_LANES=4, read once per process).  A child process traces a seeded scene with it: same bytes."""
+    import os
+    import subprocess
+    import sys
+    import zlib
+    scene, info = scenes.cathedral(3000)
+    dirs = scenes.sphere_directions(700, seed=23)
+    ctx.set_scene(scene)
+    ctx.raytrace(info["mic"], info["source"], dirs, 40, AIR_COEFFICIENTS)
+    mine = zlib.crc32(ctx.get_raw_diffuse().tobytes())
+    code = ("import sys, zlib; sys.path.insert(0, %r); import rvb_import; rvb_import.load();"
+            "from parallel_reverb_raytracer_amd import capi, scenes;"
+            "from parallel_reverb_raytracer_amd.dtypes import AIR_COEFFICIENTS;"
+            "scene, info = scenes.cathedral(3000); c = capi.Context(0); c.set_scene(scene);"
+            "c.raytrace(info['mic'], info['source'], scenes.sphere_directions(700, seed=23), 40, AIR_COEFFICIENTS);"
+            "print('CRC', zlib.crc32(c.get_raw_diffuse().tobytes()), dict(c.last_timings()).keys())") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RVB_SHADOW_LANES="4"), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("CRC")][-1]
+    assert "shadow_kernel" in line and "shadow_pair_kernel" not in line
+    assert int(line.split()[1]) == mine
 
 
 def grazing_directions(n, seed, max_slope):

@@ -241,6 +241,7 @@ int main(int argc, char ** argv)
     }
     unsigned long long verified = 0, mismatches = 0, verified_any = 0, mismatches_any = 0;
 
+    const int NQ = getenv("TRAVSIM_RAYS_PER_WAVE") ? atoi(getenv("TRAVSIM_RAYS_PER_WAVE")) : 16;   // rays that vote together (first replay only)
     const double C_NODE = 56, C_LEAF = 125, C_DONE = 115;   // incl. ~6 for the vote        // wave instructions per step (from the ISA)
     for (int p = 0; p < (verify ? 1 : 14); ++p) {
         Sim s = base;
@@ -251,11 +252,11 @@ int main(int argc, char ** argv)
         unsigned long long w_node = 0, w_leaf = 0, w_done = 0, bounces = 0, q_node_active = 0, q_leaf_active = 0, q_done_active = 0, maxstack = 0;
         std::vector<v3> hitpts; std::vector<uint32_t> hittri; std::vector<float> hitthr;
         unsigned long long skips_set = 0, skips_possible = 0;
-        for (uint64_t w = 0; w < nrays; w += 16) {
-            Query q[16]; Ray r[16];
-            enum { NODE, LEAF, DONE, IDLE } st[16];
-            int nq = (int) std::min<uint64_t>(16, nrays - w);
-            for (int i = 0; i < 16; ++i) st[i] = IDLE;
+        for (uint64_t w = 0; w < nrays; w += NQ) {
+            Query q[64]; Ray r[64];
+            enum { NODE, LEAF, DONE, IDLE } st[64];
+            int nq = (int) std::min<uint64_t>(NQ, nrays - w);
+            for (int i = 0; i < 64; ++i) st[i] = IDLE;
             for (int i = 0; i < nq; ++i) {
                 r[i].o = src; r[i].d = mk3(dirs[4 * (w + i)], dirs[4 * (w + i) + 1], dirs[4 * (w + i) + 2]); r[i].bounce = 0; r[i].alive = true;
                 s.begin(q[i], r[i].o, r[i].d, false, 0.0f);
@@ -355,7 +356,7 @@ int main(int argc, char ** argv)
                 }
             }
         }
-        const double wn = 16.0 * w_node / bounces, wl = 16.0 * w_leaf / bounces, wd = 16.0 * w_done / bounces;
+        const double wn = (double) NQ * w_node / bounces, wl = (double) NQ * w_leaf / bounces, wd = (double) NQ * w_done / bounces;
         printf("sched %d T %d | ray node %.2f leaf %.2f | wave node %.2f leaf %.2f done %.2f | active node %.1f leaf %.1f done %.1f | cost/bounce %.0f\n",
                sched, T, (double) s.node_steps / bounces, (double) s.leaf_steps / bounces, wn, wl, wd,
                (double) q_node_active / w_node, (double) q_leaf_active / w_leaf, (double) q_done_active / w_done,
@@ -377,26 +378,26 @@ int main(int argc, char ** argv)
                 Sim sh = base; sh.pol.any_order = mode;
                 unsigned long long w_node = 0, w_leaf = 0, w_done = 0, an = 0, al = 0, ad = 0;
                 const size_t J = 32;                      // records per quad in the job-loop modes
-                const size_t per_wave = 16; (void) J;
+                const size_t per_wave = getenv("TRAVSIM_RECORDS_PER_WAVE") ? atoi(getenv("TRAVSIM_RECORDS_PER_WAVE")) : 16; (void) J;
                 for (size_t w0 = 0; w0 + per_wave <= order.size(); w0 += per_wave) {
-                    Query q[16];
-                    enum { NODE, LEAF, DONE, IDLE } st[16];
-                    size_t nextj[16];
+                    Query q[64];
+                    enum { NODE, LEAF, DONE, IDLE } st[64];
+                    size_t nextj[64];
                     auto start = [&](int i) {
                         if (nextj[i] >= 1) { st[i] = IDLE; return; }
-                        const v3 pnt = hitpts[order[w0 + nextj[i] * 16 + i]];
+                        const v3 pnt = hitpts[order[w0 + nextj[i] * per_wave + i]];
                         ++nextj[i];
                         v3 b2p = mic - pnt;
                         sh.begin(q[i], pnt, normalize3(b2p), true, length3(b2p));
                         {
-                            const uint32_t rec = order[w0 + (nextj[i] - 1) * 16 + i];
+                            const uint32_t rec = order[w0 + (nextj[i] - 1) * per_wave + i];
                             const TriShade & shd = base.bs.shade[hittri[rec]];
                             const float cosine = fabsf(dot3(mk3(shd.n[0], shd.n[1], shd.n[2]), q[i].d));       // ShadowJob::next
                             if (!(getenv("TRAVSIM_SKIP") && getenv("TRAVSIM_SKIP")[0] == '0') && cosine > hitthr[rec]) q[i].skip = shd.skip_ref;
                         }
                         st[i] = NODE;
                     };
-                    for (int i = 0; i < 16; ++i) { nextj[i] = 0; start(i); }
+                    for (int i = 0; i < (int) per_wave; ++i) { nextj[i] = 0; start(i); }
                     auto classify = [&](int i) {
                         if (q[i].ref == 0xFFFFFFFFu) st[i] = DONE;
                         else st[i] = (q[i].ref & RVB_BVH_LEAF) ? LEAF : NODE;
@@ -404,7 +405,7 @@ int main(int argc, char ** argv)
                     int phase = 0;
                     for (;;) {
                         int cn = 0, cl = 0, cd = 0;
-                        for (int i = 0; i < 16; ++i) { cn += st[i] == NODE; cl += st[i] == LEAF; cd += st[i] == DONE; }
+                        for (int i = 0; i < (int) per_wave; ++i) { cn += st[i] == NODE; cl += st[i] == LEAF; cd += st[i] == DONE; }
                         if (cn + cl + cd == 0) break;
                         int act;
                         if (true) {
@@ -419,11 +420,11 @@ int main(int argc, char ** argv)
                             if (cl > best) { act = LEAF; best = cl; }
                             if (cd > best) { act = DONE; best = cd; }
                         }
-                        if (act == NODE) { ++w_node; an += cn; for (int i = 0; i < 16; ++i) if (st[i] == NODE) { sh.node_step(q[i]); classify(i); } }
-                        else if (act == LEAF) { ++w_leaf; al += cl; for (int i = 0; i < 16; ++i) if (st[i] == LEAF) { bool f = sh.leaf_step(q[i]); if (f) st[i] = DONE; else classify(i); } }
+                        if (act == NODE) { ++w_node; an += cn; for (int i = 0; i < (int) per_wave; ++i) if (st[i] == NODE) { sh.node_step(q[i]); classify(i); } }
+                        else if (act == LEAF) { ++w_leaf; al += cl; for (int i = 0; i < (int) per_wave; ++i) if (st[i] == LEAF) { bool f = sh.leaf_step(q[i]); if (f) st[i] = DONE; else classify(i); } }
                         else {
                             ++w_done; ad += cd;
-                            for (int i = 0; i < 16; ++i) if (st[i] == DONE) {
+                            for (int i = 0; i < (int) per_wave; ++i) if (st[i] == DONE) {
                                 if (verify && mode == 0 && p == 0) {            // any-hit against brute force (kernel.cpp:295)
                                     bool blocked = false;
                                     for (const BvhTri & t : sh.bs.tris) {
@@ -441,7 +442,7 @@ int main(int argc, char ** argv)
                     }
                 }
                 const double nrec = (double) (order.size() / per_wave * per_wave);
-                const double wn = 16.0 * w_node / nrec, wl = 16.0 * w_leaf / nrec, wd = 16.0 * w_done / nrec;
+                const double wn = (double) per_wave * w_node / nrec, wl = (double) per_wave * w_leaf / nrec, wd = (double) per_wave * w_done / nrec;
                 printf("   shadow mode %d | ray node %.2f leaf %.2f | wave node %.2f leaf %.2f done %.2f | active node %.1f leaf %.1f done %.1f | cost/record %.0f\n",
                        mode, sh.node_steps / nrec, sh.leaf_steps / nrec, wn, wl, wd, (double) an / w_node, (double) al / w_leaf, (double) ad / w_done,
                        wn * CS_NODE + wl * CS_LEAF + wd * CS_DONE);
