@@ -225,6 +225,15 @@ def main():
     to_host_latency_ms = (time.perf_counter() - t0) * 1e3 / solo_irs
     for c in contexts:
         c.set_concurrent_traces(pipeline.group_size(len(contexts)))
+    if pipeline.group_size(len(contexts)) > 1:
+        # the path kernel the pipeline's contexts use (two lanes per ray when two traces are in flight), also alone on the GPU
+        pair_solo = {}
+        for _ in range(2):
+            distributed.generate_ir(ctx, *trace_args, **ir_kwargs(pair_solo))
+            ctx.synchronize()
+        for k, v in pair_solo.items():
+            if k not in solo_ms:
+                solo_ms[k] = v
 
     pipeline.run(args.warmup, trace_args, ir_kwargs(None), keep)
     elapsed = timed(args.steps, ir_kwargs(kernel_ms))
@@ -278,8 +287,10 @@ def main():
         avg = {k: float(np.mean(v)) for k, v in kernel_ms.items()}
         solo = {k: float(np.mean(v)) for k, v in solo_ms.items()}       # one IR alone on the GPU (untimed pass above)
         # (the library names a timing after the kernel that ran: path_kernel / path_pair_kernel, shadow_kernel / shadow_pair_kernel)
-        trace_ms = sum(solo.get(k, 0.0) for k in ("path_kernel", "path_pair_kernel", "image_kernel", "shadow_kernel", "shadow_pair_kernel"))
-        dominant = max(solo, key=solo.get)                              # by the time the kernel itself needs
+        trace_ms = (solo.get("path_kernel", solo.get("path_pair_kernel", 0.0))          # (one IR alone: the path kernel of the solo pass)
+                    + sum(solo.get(k, 0.0) for k in ("image_kernel", "shadow_kernel", "shadow_pair_kernel")))
+        in_timed_region = {k: v for k, v in solo.items() if k in kernel_ms}     # (path_pair_kernel, not path_kernel, when traces run in pairs)
+        dominant = max(in_timed_region or solo, key=solo.get)           # by the time the kernel itself needs
         # Kernel durations for the rooflines come from the solo pass (HIP events around each launch with one IR on the GPU): in the
         # timed region the kernels of several IRs interleave and the events around a launch then span its neighbour's work as well.
         # rocprofv3 --kernel-trace --stats of `bench.py --contexts 1` agrees with them (profiles/).
@@ -358,6 +369,9 @@ def main():
                        "sharding": "ray-range shards, replicated scene, one all-reduce(sum) of [2][8][nbins] histograms",
                        "pipelining": "%d contexts per GPU take turns: traces are enqueued %d at a time, the next group before the current one is finished"
                                      % (len(contexts), max(1, len(contexts) // 2))},
+            "lanes_per_ray": {"path_kernel_in_timed_region": 2 if "path_pair_kernel" in avg else 4,
+                              "path_kernel_one_ir_alone": 4 if "path_kernel" in solo else 2, "shadow_kernel": 2 if "shadow_pair_kernel" in solo else 4,
+                              "rule": "rvb_path_lanes_for (csrc/trace_kernels.hip): two lanes per ray when rays per launch x traces in flight >= 196 608"},
             "ir_gen_wall_ms": solo_latency_ms, "ir_gen_to_host_ms": to_host_latency_ms, "contexts_per_gpu": len(contexts),
             "fast_mode" if args.mode == "exact" else "exact_mode": other_mode, "fast_vs_exact": comparison, "api_flow": api_flow,
             "trace_only_ray_bounces_per_sec": (nrays * nrefl) / (trace_ms * 1e-3) if trace_ms else None,

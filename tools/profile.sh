@@ -2,9 +2,11 @@
 # Profiles of the default bench command on the GPU box (run through gpurun): one kernel-trace + stats pass and separate
 # PMC passes (a pass never mixes --pmc with a trace domain other than --kernel-trace; FETCH_SIZE and WRITE_SIZE do not fit
 # in one pass — MI355X_MICROARCH.md "rocprofv3 PMC slots").  Raw output under gpurun_out/<tag>_*, summaries by
-# tools/profile_summary.py.        tools/profile.sh <tag>
+# tools/profile_summary.py.        tools/profile.sh <tag> [ENV=value ...]
 set -u
 tag=$1
+shift
+for kv in "$@"; do export "$kv"; done      # extra environment for every pass, e.g. RVB_PATH_LANES=2 (the two-lane path kernel alone on the GPU)
 cd "${GRAFT_REPO_ROOT:-$PWD}"
 root=$PWD
 export TMPDIR=/tmp
