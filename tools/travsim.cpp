@@ -242,7 +242,9 @@ int main(int argc, char ** argv)
     unsigned long long verified = 0, mismatches = 0, verified_any = 0, mismatches_any = 0;
 
     const int NQ = getenv("TRAVSIM_RAYS_PER_WAVE") ? atoi(getenv("TRAVSIM_RAYS_PER_WAVE")) : 16;   // rays that vote together (first replay only)
-    const double C_NODE = 56, C_LEAF = 125, C_DONE = 115;   // incl. ~6 for the vote        // wave instructions per step (from the ISA)
+    // wave instructions per step (from the ISA, incl. ~6 for the vote): quad kernel by default, TRAVSIM_COSTS="79,146,75" = pair kernel
+    double C_NODE = 56, C_LEAF = 125, C_DONE = 115;
+    if (getenv("TRAVSIM_COSTS")) sscanf(getenv("TRAVSIM_COSTS"), "%lf,%lf,%lf", &C_NODE, &C_LEAF, &C_DONE);
     for (int p = 0; p < (verify ? 1 : 14); ++p) {
         Sim s = base;
         s.pol.stack_dist = 0; s.pol.sorted_push = 0; s.pol.postpone = 0;
