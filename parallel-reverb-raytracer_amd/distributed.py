@@ -106,7 +106,7 @@ def begin_ir(tracer, mic, source, nreflections, air, ray_offset=0):
 
 def generate_ir(tracer, mic, source, nreflections, air, speakers_dir=None, speakers_coeff=None, sample_rate=44100.0,
                 trim_predelay=True, mode=capi.IR_FAST, rank=0, world=1, ray_offset=0, device="cpu",
-                which=capi.IR_ALL, remove_direct=False, on_stage=None, begun=False, model=None, collectives=None):
+                which=capi.IR_ALL, remove_direct=False, on_stage=None, begun=False, model=None, collectives=None, defer=False):
     """One impulse response from the rays already set on `tracer`.  Returns (hist tensor
     [nchannels][8][nbins] — identical on every rank —, info dict).
 
@@ -118,7 +118,11 @@ def generate_ir(tracer, mic, source, nreflections, air, speakers_dir=None, speak
 
     begun=True: begin_ir(tracer, ...) has already enqueued this IR's trace.  A caller with two contexts per GPU
     calls begin_ir on the second before generate_ir(..., begun=True) on the first, so that one IR's trace (VALU-bound)
-    runs beside the other's record grouping, binning, host work and collectives (IrPipeline below)."""
+    runs beside the other's record grouping, binning, host work and collectives (IrPipeline below).
+
+    defer=True: returns (hist, info, finish) as soon as the binning is ENQUEUED; finish() waits for it (and runs the all-reduce).
+    A caller that finishes several IRs enqueues all their binning stages first, so that they run side by side instead of each
+    waiting for the one before (IrPipeline: the stages of a group)."""
     import torch
     import torch.distributed as dist
 
@@ -167,12 +171,19 @@ def generate_ir(tracer, mic, source, nreflections, air, speakers_dir=None, speak
     hist = torch.zeros((model.nchannels, 8, nbins), device=device, dtype=torch.float32)
     if contributes:                                      # (the tracer's stream waits for torch's zero fill by an event)
         tracer.ir_accumulate_tensor(predelay, sample_rate, nbins, mode, hist)
-    if on_stage:
-        on_stage("accumulate", tracer)
-    tracer.synchronize()
-    if collectives:
-        dist.all_reduce(hist, op=dist.ReduceOp.SUM)      # RCCL over xGMI: [channels][8][nbins] floats
-    return hist, {"nbins": nbins, "predelay": predelay, "images": int(images.shape[0]), "max_time": hi}
+    info = {"nbins": nbins, "predelay": predelay, "images": int(images.shape[0]), "max_time": hi}
+
+    def finish():
+        if on_stage:
+            on_stage("accumulate", tracer)
+        tracer.synchronize()
+        if collectives:
+            dist.all_reduce(hist, op=dist.ReduceOp.SUM)  # RCCL over xGMI: [channels][8][nbins] floats
+
+    if defer:
+        return hist, info, finish
+    finish()
+    return hist, info
 
 
 class IrPipeline:
@@ -229,13 +240,30 @@ class IrPipeline:
                 begun_upto[0] += 1
 
         begin_upto(group if ahead <= 0 else 1 + ahead)
+        if n > 1 and ahead <= 0:
+            # group by group: the traces of the group after next are enqueued, then the binning stages of ALL IRs of this group
+            # (each needs its own trace's image-source candidates on the host first), and only then the host waits for them — the
+            # stages of a group run side by side, beside the next group's path kernels, instead of one after the other
+            for g0 in range(0, len(jobs), group):
+                begin_upto((g0 // group + 2) * group)
+                pending = []
+                for i in range(g0, min(g0 + group, len(jobs))):
+                    slot = (first + i) % n
+                    trace_args, ir_kwargs = jobs[i]
+                    began = self.begun[slot]
+                    self.begun[slot] = False
+                    hist, info, finish = generate_ir(self.tracers[slot], *trace_args, begun=began, defer=True, **ir_kwargs)
+                    pending.append((hist, info, finish, self.tracers[slot]))
+                for hist, info, finish, tracer in pending:
+                    finish()
+                    if on_result:
+                        on_result(hist, info, tracer)
+            self.next_slot = (first + len(jobs)) % n
+            return
         for i, (trace_args, ir_kwargs) in enumerate(jobs):
             slot = (first + i) % n
             if n > 1:
-                if ahead > 0:
-                    begin_upto(i + 1 + ahead)
-                elif i % group == 0:
-                    begin_upto((i // group + 2) * group)
+                begin_upto(i + 1 + ahead)
             else:
                 begin_upto(i + 1)
             began = self.begun[slot]
