@@ -88,6 +88,7 @@ struct rvb_ctx {
     AttenuationModel model;
     int which = RVB_IR_ALL;
     DevBuf images, hrtf_table, acc, keys_a, keys_b, vals_a, vals_b, sort_temp, scratch_in, scratch_out, hist, bin_starts;
+    DevBuf own_sort_temp, own_sort_keys, own_sort_values;      // csrc/radix_sort.hip: tile counters, the intermediate (key, value) pair
     uint64_t nimages = 0;
     std::vector<rvb_impulse> images_host;
 
@@ -123,6 +124,10 @@ struct rvb_ctx {
     void reset_timings() { timings.clear(); events_used = 0; }
     bool timing_open = false;
 };
+
+static bool own_sort_enabled();
+static int own_sort(rvb_ctx * ctx, const uint32_t * keys, uint32_t value_base, uint64_t n, int begin_bit, int end_bit,
+                    uint32_t * keys_out, uint32_t * values_out, bool want_keys);
 
 namespace {
 
@@ -223,7 +228,7 @@ void rvb_destroy(rvb_ctx * ctx)
     if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
     for (DevBuf * b : {&ctx->nodes, &ctx->tris, &ctx->shade, &ctx->corners, &ctx->surfaces, &ctx->leafpos, &ctx->sort_keys, &ctx->sort_scratch, &ctx->sort_order, &ctx->group_temp, &ctx->directions_own, &ctx->impulses,
                        &ctx->early, &ctx->candidates, &ctx->small, &ctx->stamps, &ctx->images, &ctx->hrtf_table, &ctx->acc, &ctx->keys_a,
-                       &ctx->keys_b, &ctx->vals_a, &ctx->vals_b, &ctx->sort_temp, &ctx->scratch_in, &ctx->scratch_out, &ctx->hist, &ctx->bin_starts,
+                       &ctx->keys_b, &ctx->vals_a, &ctx->vals_b, &ctx->sort_temp, &ctx->scratch_in, &ctx->scratch_out, &ctx->hist, &ctx->bin_starts, &ctx->own_sort_temp, &ctx->own_sort_keys, &ctx->own_sort_values,
                        &ctx->pair_geom, &ctx->pair_direct, &ctx->pair_range})
         b->release();
     for (rvb_ctx::CopyLane & l : ctx->copy_lanes) {
@@ -501,10 +506,17 @@ static int trace_common(rvb_ctx * ctx, const float * mics, const float * sources
         RVB_HIP(ctx, hipGetLastError());
         // one grouping per pair (a pair's shadow rays share a microphone; records are [pair][ray][bounce])
         const uint64_t per_pair = ctx->nrays * nreflections;
-        for (uint64_t p = 0; p < npairs; ++p)
-            RVB_HIP(ctx, rvb_group_records(ctx->group_temp.p, ctx->group_temp.cap, a.sort_keys + p * per_pair,
-                                           ctx->sort_scratch.as<uint32_t>() + p * per_pair, a.sort_order + p * per_pair, per_pair,
-                                           (uint32_t) (p * per_pair), std::max(0, key_bits - group_bits), key_bits, ctx->stream));
+        for (uint64_t p = 0; p < npairs; ++p) {
+            if (own_sort_enabled()) {
+                const int rc = own_sort(ctx, a.sort_keys + p * per_pair, (uint32_t) (p * per_pair), per_pair, std::max(0, key_bits - group_bits), key_bits,
+                                        ctx->sort_scratch.as<uint32_t>() + p * per_pair, a.sort_order + p * per_pair, false);
+                if (rc != RVB_OK) return rc;
+            } else {
+                RVB_HIP(ctx, rvb_group_records(ctx->group_temp.p, ctx->group_temp.cap, a.sort_keys + p * per_pair,
+                                               ctx->sort_scratch.as<uint32_t>() + p * per_pair, a.sort_order + p * per_pair, per_pair,
+                                               (uint32_t) (p * per_pair), std::max(0, key_bits - group_bits), key_bits, ctx->stream));
+            }
+        }
         ctx->end_timing();
     }
     RVB_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_done, 0));
@@ -793,6 +805,40 @@ int rvb_attenuate_hrtf_device(rvb_ctx * ctx, const float mic[3], const void * d_
     return RVB_OK;
 }
 
+// rocPRIM's radix sort unless RVB_SORT=own asks for the library's own (csrc/radix_sort.hip: same results, kernels that fit beside
+// resident path waves; measured 3-4 % slower per IR in the bench pipeline, see the file's header).
+static bool own_sort_enabled()
+{
+    static const bool own = getenv("RVB_SORT") && std::strcmp(getenv("RVB_SORT"), "own") == 0;
+    return own;
+}
+
+// (keys[i], value_base + i) sorted on key bits [begin_bit, end_bit) into (keys_out, values_out); keys_out is always a buffer of n
+// words (intermediate passes use it) but holds the sorted keys only if want_keys.
+static int own_sort(rvb_ctx * ctx, const uint32_t * keys, uint32_t value_base, uint64_t n, int begin_bit, int end_bit,
+                    uint32_t * keys_out, uint32_t * values_out, bool want_keys)
+{
+    if (n == 0 || end_bit <= begin_bit) return RVB_OK;
+    const int passes = (end_bit - begin_bit + 7) / 8;
+    RVB_HIP(ctx, ctx->own_sort_temp.ensure(rvb_radix_sort_temp_bytes(n)));
+    uint32_t * tmp_k = nullptr, * tmp_v = nullptr;
+    if (passes > 1) {
+        RVB_HIP(ctx, ctx->own_sort_keys.ensure(n * 4));
+        RVB_HIP(ctx, ctx->own_sort_values.ensure(n * 4));
+        tmp_k = ctx->own_sort_keys.as<uint32_t>();
+        tmp_v = ctx->own_sort_values.as<uint32_t>();
+    }
+    // passes alternate A, B, A, ...: the last one must land in the caller's buffers
+    const bool last_in_b = ((passes - 1) & 1) != 0;
+    uint32_t * ka = last_in_b ? tmp_k : keys_out, * va = last_in_b ? tmp_v : values_out;
+    uint32_t * kb = last_in_b ? keys_out : tmp_k, * vb = last_in_b ? values_out : tmp_v;
+    const uint32_t * ks = nullptr, * vs = nullptr;
+    RVB_HIP(ctx, rvb_radix_sort_pairs(ctx->own_sort_temp.p, ctx->own_sort_temp.cap, keys, nullptr, value_base, ka, va, kb, vb, n,
+                                      begin_bit, end_bit, want_keys, &ks, &vs, ctx->stream));
+    if (vs != values_out || (want_keys && ks != keys_out)) return fail(ctx, RVB_ERR_HIP, "internal error: radix sort result in the wrong buffer");
+    return RVB_OK;
+}
+
 static int ensure_sort_buffers(rvb_ctx * ctx, uint64_t n)
 {
     RVB_HIP(ctx, ctx->keys_a.ensure(n * 4));
@@ -823,8 +869,13 @@ static int flatten_keys(rvb_ctx * ctx, const rvb_attenuated_impulse * d_in, uint
 static int flatten_sum(rvb_ctx * ctx, const rvb_attenuated_impulse * d_in, uint64_t n, uint64_t bins, float * out)
 {
     RVB_HIP(ctx, ctx->hist.ensure(bins * 8 * sizeof(float)));
-    rvb_sort_pairs(ctx->sort_temp.p, ctx->sort_temp.cap, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(),
-                   ctx->vals_a.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), n, key_bits_for(bins), ctx->stream);
+    if (own_sort_enabled()) {       // (the values the key pass wrote are the impulse indices 0 .. n-1: implicit)
+        const int rc = own_sort(ctx, ctx->keys_a.as<uint32_t>(), 0u, n, 0, key_bits_for(bins), ctx->keys_b.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), true);
+        if (rc != RVB_OK) return rc;
+    } else {
+        rvb_sort_pairs(ctx->sort_temp.p, ctx->sort_temp.cap, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(),
+                       ctx->vals_a.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), n, key_bits_for(bins), ctx->stream);
+    }
     RVB_HIP(ctx, ctx->bin_starts.ensure(bins * 8));
     RVB_HIP(ctx, hipMemsetAsync(ctx->bin_starts.p, 0xFF, bins * 4, ctx->stream));
     rvb_launch_bin_starts(ctx->keys_b.as<uint32_t>(), n, bins, ctx->bin_starts.as<uint32_t>(), ctx->bin_starts.as<uint32_t>() + bins, ctx->stream);
@@ -1181,8 +1232,13 @@ int rvb_ir_accumulate(rvb_ctx * ctx, float predelay, float sample_rate, uint64_t
                                 ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), ctx->stream);
             rvb_launch_bin_keys(m, ch, ctx->images.as<rvb_impulse>(), nimages, ndiffuse, predelay, sample_rate, sentinel,
                                 ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), ctx->stream);
-            rvb_sort_pairs(ctx->sort_temp.p, ctx->sort_temp.cap, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(),
-                           ctx->vals_a.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), n, bits, ctx->stream);
+            if (own_sort_enabled()) {
+                const int rc = own_sort(ctx, ctx->keys_a.as<uint32_t>(), 0u, n, 0, bits, ctx->keys_b.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), true);
+                if (rc != RVB_OK) return rc;
+            } else {
+                rvb_sort_pairs(ctx->sort_temp.p, ctx->sort_temp.cap, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(),
+                               ctx->vals_a.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), n, bits, ctx->stream);
+            }
             RVB_HIP(ctx, hipMemsetAsync(ctx->bin_starts.p, 0xFF, nbins * 4, ctx->stream));
             rvb_launch_bin_starts(ctx->keys_b.as<uint32_t>(), n, nbins, ctx->bin_starts.as<uint32_t>(), ctx->bin_starts.as<uint32_t>() + nbins, ctx->stream);
             rvb_launch_ordered_sum(m, ch, m.hrtf ? 1u : m.nchannels, ir_diffuse(ctx), ndiffuse, ctx->images.as<rvb_impulse>(), nimages,

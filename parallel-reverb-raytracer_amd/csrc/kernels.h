@@ -109,6 +109,12 @@ void rvb_launch_flat_ordered_sum(const rvb_attenuated_impulse * in, const uint32
                                  const uint32_t * starts, uint64_t n, uint64_t nbins, float * out, hipStream_t s);
 void rvb_launch_fix_predelay(rvb_attenuated_impulse * a, uint64_t n, float seconds, hipStream_t s);
 // stable sort of (key, value) pairs by key (device radix sort); temp storage managed by the caller
+// csrc/radix_sort.hip: stable LSD radix sort whose kernels fit beside resident path waves (single-wave workgroups, <= 32 VGPRs)
+size_t rvb_radix_sort_temp_bytes(uint64_t n);
+hipError_t rvb_radix_sort_pairs(void * temp, size_t temp_bytes, const uint32_t * keys, const uint32_t * values, uint32_t value_base,
+                                uint32_t * keys_a, uint32_t * values_a, uint32_t * keys_b, uint32_t * values_b, uint64_t n,
+                                int begin_bit, int end_bit, bool want_keys, const uint32_t ** keys_sorted, const uint32_t ** values_sorted,
+                                hipStream_t s);
 size_t rvb_sort_temp_bytes(uint64_t n);
 void rvb_sort_pairs(void * temp, size_t temp_bytes, const uint32_t * keys_in, uint32_t * keys_out,
                     const uint32_t * values_in, uint32_t * values_out, uint64_t n, int key_bits, hipStream_t s);

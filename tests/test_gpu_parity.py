@@ -130,6 +130,30 @@ def test_quad_shadow_kernel_gives_the_same_bytes(ctx):
     assert int(line.split()[1]) == mine
 
 
+def test_own_radix_sort_gives_the_same_bytes(ctx, oracle):
+    """RVB_SORT=own (csrc/radix_sort.hip instead of rocPRIM's radix sort, read once per process) in a child process: the grouped
+    trace and the exact-mode histogram of a seeded scene are the bytes this process gets."""
+    import os
+    import subprocess
+    import sys
+    import zlib
+    code = ("import sys, zlib, numpy as np; sys.path.insert(0, %r); import rvb_import; rvb_import.load();"
+            "from parallel_reverb_raytracer_amd import capi, scenes;"
+            "from parallel_reverb_raytracer_amd.dtypes import AIR_COEFFICIENTS;"
+            "scene, info = scenes.cathedral(3000); c = capi.Context(0); c.set_scene(scene);"
+            "c.raytrace(info['mic'], info['source'], scenes.sphere_directions(5000, seed=29), 30, AIR_COEFFICIENTS);"
+            "c.ir_configure_speakers(info['mic'], [(-1, 0, -1), (1, 0, -1)], [0.5, 0.5], capi.IR_ALL, c.get_raw_images(False));"
+            "hist = c.ir_download(True, 44100.0, capi.IR_EXACT);"
+            "print('CRC', zlib.crc32(c.get_raw_diffuse().tobytes()), zlib.crc32(np.ascontiguousarray(hist).tobytes()), hist.shape)"
+            ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    crcs = []
+    for sort in ("own", "rocprim"):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RVB_SORT=sort), capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        crcs.append([l for l in out.stdout.splitlines() if l.startswith("CRC")][-1])
+    assert crcs[0] == crcs[1]
+
+
 def grazing_directions(n, seed, max_slope):
     """Unit vectors within `max_slope` of the horizontal plane, random azimuth: rays that skim the floor and ceiling of a room
     and meet their triangles nearly edge-on, where |det| sits just above the reference's 1e-4 rejection threshold and the float
