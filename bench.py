@@ -339,6 +339,23 @@ def main():
                 if v.get("valu_lane_utilisation") is not None:
                     entry["useful_lane_fraction"] = v["valu_lane_utilisation"]
                 valu[k] = entry
+        # the whole step in the timed region: issue-model time of every kernel of one IR (per launch x launches per IR, the path kernel
+        # being the one the timed region ran) over the measured time per IR = the share of the time the SIMDs issue VALU work
+        if pmc and args.mode == "exact":
+            irs = max(1, int(loaded.get("irs_in_command") or 0))
+            ran_pairs = "path_pair_kernel" in avg
+            per_ir, parts = 0.0, {}
+            for k, v in pmc.items():
+                if not v.get("valu_issue_model_ms") or k == "attenuate_kernel":
+                    continue
+                if k == ("path_kernel" if ran_pairs else "path_pair_kernel"):
+                    continue
+                launches_per_ir = 1.0 if k in ("path_kernel", "path_pair_kernel") else v.get("_launches", irs) / irs
+                parts[k] = v["valu_issue_model_ms"] * launches_per_ir
+                per_ir += parts[k]
+            valu["whole_step"] = {"bound": "valu_issue", "issue_model_ms_per_ir": per_ir, "ms_per_ir_timed_region": ms_per_step,
+                                  "frac": per_ir / ms_per_step, "issue_model_ms_by_kernel": parts, "numerators": from_profile,
+                                  "note": "sum over the kernels of one IR of (VALU issue-model time per launch x launches per IR) / measured time per IR"}
         stream = {}
         algorithmic = {"shadow_kernel": 128.0 * nrays * nrefl,          # 64-byte work record read, 64-byte Impulse written
                        "shadow_pair_kernel": 128.0 * nrays * nrefl,

@@ -244,8 +244,9 @@ class IrPipeline:
             # group by group: the traces of the group after next are enqueued, then the binning stages of ALL IRs of this group
             # (each needs its own trace's image-source candidates on the host first), and only then the host waits for them — the
             # stages of a group run side by side, beside the next group's path kernels, instead of one after the other
+            in_flight = max(2, n // group)                   # groups whose traces are enqueued at a time (each context holds one IR)
             for g0 in range(0, len(jobs), group):
-                begin_upto((g0 // group + 2) * group)
+                begin_upto((g0 // group + in_flight) * group)
                 pending = []
                 for i in range(g0, min(g0 + group, len(jobs))):
                     slot = (first + i) % n
