@@ -31,6 +31,9 @@
 #ifndef RVB_PROBE_NO_STORES
 #define RVB_PROBE_NO_STORES 0
 #endif
+#ifndef RVB_QUAD_SELECT
+#define RVB_QUAD_SELECT 1      // slab_select (near / far plane by the direction's sign) in the four-lane path kernel as well
+#endif
 #ifndef RVB_SHADOW_JOBS
 #define RVB_SHADOW_JOBS 0
 #endif
@@ -403,10 +406,19 @@ __device__ __forceinline__ void traverse_jobs_vote(const SceneDev & sc, uint32_t
     float ix = 0.0f, iy = 0.0f, iz = 0.0f, oix = 0.0f, oiy = 0.0f, oiz = 0.0f;
     unsigned long long best_key = NO_HIT_KEY;                              // (distance bits, triangle index) of the closest hit so far
     uint32_t sp = 0, ref = IDLE;
+#if RVB_QUAD_SELECT
+    uint32_t selx = 0, sely = 0, selz = 0;
+#define RVB_QUAD_SEL_SET() selx = slab_selector(ix); sely = slab_selector(iy); selz = slab_selector(iz);
+#define RVB_QUAD_SLAB(n, tn) slab_select(n, ix, iy, iz, oix, oiy, oiz, selx, sely, selz, limit, neg_cull, job.skip_ref(), tn)
+#else
+#define RVB_QUAD_SEL_SET()
+#define RVB_QUAD_SLAB(n, tn) slab(n, ix, iy, iz, oix, oiy, oiz, limit, neg_cull, job.skip_ref(), tn)
+#endif
 #define RVB_RESET_QUERY()                                                         \
     {                                                                             \
         ix = clamp_inv(d.x); iy = clamp_inv(d.y); iz = clamp_inv(d.z);            \
         oix = o.x * ix; oiy = o.y * iy; oiz = o.z * iz;                           \
+        RVB_QUAD_SEL_SET()                                                        \
         best_key = NO_HIT_KEY; sp = 0; ref = 0;                                   \
     }
     if (job.next(o, d, tmax)) RVB_RESET_QUERY()
@@ -428,7 +440,7 @@ __device__ __forceinline__ void traverse_jobs_vote(const SceneDev & sc, uint32_t
 #endif
                 const float limit = fmaf(__uint_as_float((uint32_t) (best_key >> 32)), cull_scale, sc.cull_abs);
                 float tn;
-                const bool ok = slab(n, ix, iy, iz, oix, oiy, oiz, limit, neg_cull, job.skip_ref(), tn);
+                const bool ok = RVB_QUAD_SLAB(n, tn);
                 const uint32_t cref = n.w;
                 const uint32_t key = ok ? ((__float_as_uint(fmaxf(tn, 0.0f)) & ~3u) | c) : NONE;
                 uint32_t kmin = min(key, dpp_u<QP_SWAP1>(key));
@@ -884,8 +896,11 @@ struct PathJob {
 
 // 64 VGPRs = 8 waves per SIMD: one resident round holds 8 x 1024 x 16 = 131 072 rays, so the 125 k rays per GPU of
 // workload C3 still run as one round (at 72 VGPRs / 7 waves they took 5.1 ms instead of 4.3 ms).
-template <bool SURF_LDS>
-__global__ __launch_bounds__(WAVE, 8) void path_kernel(TraceArgs a)
+// WAVES = 7 (72 VGPRs) is the build for launches that fit in seven waves per SIMD (<= 114 688 rays: the 100 k rays of workload C2 are
+// 6.1 waves per SIMD): with the registers of slab_select and no spill, 3.66 -> 3.50 ms at C2; the 8-wave build keeps larger launches
+// (up to 131 072 rays) in one resident round (3.66 -> 3.58 ms at C2 with slab_select and two spilled registers).
+template <bool SURF_LDS, int WAVES>
+__global__ __launch_bounds__(WAVE, WAVES) void path_kernel(TraceArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t stack_lds[];   // [stack_entries][QUADS_PER_BLOCK]
     const uint32_t q = threadIdx.x >> 2;
@@ -1440,8 +1455,14 @@ void rvb_launch_path(const TraceArgs & a, hipStream_t s)
         return;
     }
     const unsigned blocks = (unsigned) ((a.nrays + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK);
-    if (a.lds_surfaces) hipLaunchKernelGGL(path_kernel<true>, dim3(blocks), dim3(WAVE), quad_kernel_lds_bytes(a), s, a);
-    else hipLaunchKernelGGL(path_kernel<false>, dim3(blocks), dim3(WAVE), quad_kernel_lds_bytes(a), s, a);
+    const bool seven = a.nrays <= 7ull * 1024ull * QUADS_PER_BLOCK;      // fits in seven waves per SIMD: the 72-register build
+    if (a.lds_surfaces) {
+        if (seven) hipLaunchKernelGGL((path_kernel<true, 7>), dim3(blocks), dim3(WAVE), quad_kernel_lds_bytes(a), s, a);
+        else hipLaunchKernelGGL((path_kernel<true, 8>), dim3(blocks), dim3(WAVE), quad_kernel_lds_bytes(a), s, a);
+    } else {
+        if (seven) hipLaunchKernelGGL((path_kernel<false, 7>), dim3(blocks), dim3(WAVE), quad_kernel_lds_bytes(a), s, a);
+        else hipLaunchKernelGGL((path_kernel<false, 8>), dim3(blocks), dim3(WAVE), quad_kernel_lds_bytes(a), s, a);
+    }
 }
 
 void rvb_launch_images(const TraceArgs & a, hipStream_t s)
