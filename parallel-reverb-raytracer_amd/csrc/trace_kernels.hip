@@ -1,23 +1,25 @@
 // trace_kernels.hip — the per-ray trace of reference rayverb/kernel.cpp:304-503 (kernel
 // `raytrace`), re-organised for CDNA4 as three kernels over one 4-wide BVH:
 //
-//   path_kernel    the inherently sequential chain closest hit -> reflect (kernel.cpp:359-375,
-//                  :459-461, :478, :492-501).  Latency-bound: FOUR LANES PER RAY, so that 100k rays
-//                  are 6250 waves instead of 1563 and the chip has enough waves to hide the
-//                  dependent node fetches.  Per bounce it leaves a 64-byte work record in the
-//                  ray's Impulse slot.
+//   path_kernel / path_pair_kernel
+//                  the inherently sequential chain closest hit -> reflect (kernel.cpp:359-375,
+//                  :459-461, :478, :492-501).  Latency-bound: SEVERAL LANES PER RAY — four (100k rays are
+//                  6250 waves instead of 1563: enough waves to hide the dependent node fetches) or two
+//                  (a quarter fewer instructions per bounce; chosen when the rays in flight fill the chip
+//                  anyway, rvb_path_lanes_for).  Per bounce it leaves a 64-byte work record in the ray's
+//                  Impulse slot.
 //   image_kernel   one lane per ray: image-source validation of its first nine bounces (kernel.cpp:379-457),
 //                  the chain of mirrored triangles grown bounce by bounce.  Its inputs are only the triangles
 //                  the ray hit, so it runs beside the record grouping instead of inside the ray's loop.
-//   shadow_kernel  four lanes per (ray, bounce): the diffuse shadow ray to the microphone and the
+//   shadow_pair_kernel (shadow_kernel: the four-lane form, kept for measurements)
+//                  two lanes per (ray, bounce): the diffuse shadow ray to the microphone and the
 //                  final Impulse (kernel.cpp:463-490).  nrays*nreflections independent any-hit
 //                  queries: this is where the chip fills up.
 //
-// Quad-cooperative traversal: the four lanes of a quad own the four children of a node (one
-// contiguous 64-byte half line per visit, one 16-byte load per lane) and the up-to-four triangles
-// of a leaf; they combine results with DPP quad_perm moves, never through memory.  (Nodes are 64 bytes:
-// binary16 boxes rounded outward, one 16-byte load per lane per visit.)  The per-ray
-// stack lives in LDS, 4 bytes per entry.  Every triangle test is the reference's Möller–Trumbore
+// Lane-cooperative traversal: the lanes of a ray own the four children of a node (one contiguous 64-byte
+// half line per visit, 16-byte loads) and the up-to-four triangles of a leaf; they combine results with
+// DPP quad_perm moves, never through memory.  (Nodes are 64 bytes: binary16 boxes rounded outward.)  The
+// per-ray stack lives in LDS, 4 bytes per entry.  Every triangle test is the reference's Möller–Trumbore
 // arithmetic (rvb_math.h); the BVH only prunes, so a query returns the brute-force answer.
 #include "kernels.h"
 #include "rvb_math.h"
