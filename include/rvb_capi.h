@@ -108,6 +108,14 @@ int rvb_trace(rvb_ctx * ctx, const float mic[3], const float source[3],
  * 100 k, 2.9 ms at 400 k); results are bit-identical to tracing the pairs one by one. */
 int rvb_trace_pairs(rvb_ctx * ctx, const float * mics, const float * sources, uint64_t npairs,
                     uint64_t nreflections, const float air_coefficient[8], uint64_t ray_offset);
+
+/* rvb_trace on several contexts of one device at once (at most 4): same results as calling rvb_trace(ctxs[i], mics + 3 i, sources + 3 i,
+ * nreflections, air_coefficient, ray_offsets ? ray_offsets[i] : 0) one after the other, but the path kernels of the group are ONE launch
+ * when the rays of the group fill the chip (their waves are then scheduled together instead of one launch after the other's).  Every
+ * context keeps its own rays, buffers and stream; what follows the path kernel runs per context as in rvb_trace.  No reference
+ * counterpart (the reference traces one 4096-ray group at a time, rayverb.cpp:586-591). */
+int rvb_trace_group(rvb_ctx ** ctxs, uint64_t count, const float * mics, const float * sources, uint64_t nreflections,
+                    const float air_coefficient[8], const uint64_t * ray_offsets);
 /* Chooses the pair that rvb_get_direct and the rvb_ir_* calls below work on (pair 0 after a trace). */
 int rvb_ir_select_pair(rvb_ctx * ctx, uint64_t pair);
 

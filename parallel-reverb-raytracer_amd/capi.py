@@ -24,7 +24,7 @@ IR_FAST, IR_EXACT = 0, 1
 # every symbol include/rvb_capi.h declares
 SYMBOLS = [
     "rvb_create", "rvb_destroy", "rvb_last_error", "rvb_synchronize", "rvb_wait_for_event", "rvb_device_info",
-    "rvb_set_scene", "rvb_scene_info", "rvb_set_directions", "rvb_set_directions_device", "rvb_set_concurrent_traces", "rvb_trace",
+    "rvb_set_scene", "rvb_scene_info", "rvb_set_directions", "rvb_set_directions_device", "rvb_set_concurrent_traces", "rvb_trace", "rvb_trace_group",
     "rvb_trace_pairs", "rvb_ir_select_pair",
     "rvb_get_diffuse", "rvb_diffuse_device", "rvb_get_direct", "rvb_get_image_candidates", "rvb_merge_images",
     "rvb_attenuate_speaker", "rvb_attenuate_speaker_device", "rvb_attenuate_hrtf", "rvb_attenuate_hrtf_device", "rvb_flatten",
@@ -169,6 +169,19 @@ class Context:
     def set_directions_device(self, device_pointer, nrays):
         self._check(self.lib.rvb_set_directions_device(self.handle, _vp(device_pointer), _u64(nrays)))
         self.nrays = nrays
+
+    @staticmethod
+    def trace_group(contexts, mics, sources, nreflections, air, ray_offsets=None):
+        """rvb_trace on several contexts of one device with ONE path-kernel launch (rvb_trace_group)."""
+        n = len(contexts)
+        handles = (ctypes.c_void_p * n)(*[c.handle for c in contexts])
+        m = np.ascontiguousarray(np.asarray(mics, dtype=np.float32).reshape(n, 3))
+        s = np.ascontiguousarray(np.asarray(sources, dtype=np.float32).reshape(n, 3))
+        offs = (ctypes.c_uint64 * n)(*[int(o) for o in (ray_offsets if ray_offsets is not None else [0] * n)])
+        contexts[0]._check(contexts[0].lib.rvb_trace_group(handles, _u64(n), _ptr(m), _ptr(s), _u64(nreflections), _f8(air), offs))
+        for c in contexts:
+            c.nreflections = int(nreflections)
+            c.npairs = 1
 
     def set_concurrent_traces(self, traces):
         """Hint: traces of this size the caller keeps in flight on the device at a time (rvb_set_concurrent_traces)."""

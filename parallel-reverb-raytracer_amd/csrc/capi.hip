@@ -43,6 +43,7 @@ struct rvb_ctx {
     hipStream_t stream = nullptr;
     hipStream_t side_stream = nullptr;          // image_kernel runs here, beside the record grouping
     hipEvent_t path_done = nullptr, side_done = nullptr;
+    hipEvent_t prep_done = nullptr, group_done = nullptr;      // rvb_trace_group: this context's fills are enqueued / the group's path kernel is
     std::string error;
     std::string arch;
     int compute_units = 0;
@@ -211,6 +212,8 @@ int rvb_create(rvb_ctx ** out, int device, unsigned flags)
         (e = hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, prio_least)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->path_done, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->side_done, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->prep_done, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->group_done, hipEventDisableTiming)) != hipSuccess ||
         (e = ctx->small.ensure(kSmallBytes)) != hipSuccess) {
         std::string what = std::string("rvb_create: ") + hipGetErrorString(e);
         delete ctx;
@@ -240,6 +243,8 @@ void rvb_destroy(rvb_ctx * ctx)
     for (hipEvent_t e : ctx->event_pool) (void) hipEventDestroy(e);
     if (ctx->path_done) (void) hipEventDestroy(ctx->path_done);
     if (ctx->side_done) (void) hipEventDestroy(ctx->side_done);
+    if (ctx->prep_done) (void) hipEventDestroy(ctx->prep_done);
+    if (ctx->group_done) (void) hipEventDestroy(ctx->group_done);
     if (ctx->side_stream) { (void) hipStreamSynchronize(ctx->side_stream); (void) hipStreamDestroy(ctx->side_stream); }
     if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -377,8 +382,16 @@ int rvb_set_concurrent_traces(rvb_ctx * ctx, uint32_t traces)
     return RVB_OK;
 }
 
-static int trace_common(rvb_ctx * ctx, const float * mics, const float * sources, uint64_t npairs, uint64_t nreflections,
-                        const float air_coefficient[8], uint64_t ray_offset)
+// A trace in three steps — buffers, fills and kernel arguments; the path kernel; everything after it — so that rvb_trace_group can put
+// the path kernels of several contexts into ONE launch.
+struct TracePlan {
+    TraceArgs a;
+    uint64_t npairs = 1, nrays = 0, nreflections = 0;
+    int key_bits = 1;
+};
+
+static int trace_prepare(rvb_ctx * ctx, const float * mics, const float * sources, uint64_t npairs, uint64_t nreflections,
+                         const float air_coefficient[8], uint64_t ray_offset, uint64_t rays_in_flight, TracePlan & plan)
 {
     if (!ctx->have_scene) return fail(ctx, RVB_ERR_STATE, "rvb_trace: rvb_set_scene has not been called");
     if (!ctx->directions && ctx->nrays) return fail(ctx, RVB_ERR_STATE, "rvb_trace: no directions");
@@ -399,7 +412,7 @@ static int trace_common(rvb_ctx * ctx, const float * mics, const float * sources
     RVB_HIP(ctx, hipMemsetAsync(ctx->small.p, 0, kSmallBytes, ctx->stream));
     RVB_HIP(ctx, hipMemsetAsync(ctx->small.as<char>() + kSmallTraceRange, 0xFF, 4, ctx->stream));
 
-    TraceArgs a;
+    TraceArgs & a = plan.a;
     a.scene = ctx->scene;
     a.directions = ctx->directions;
     a.impulses = ctx->impulses.as<rvb_impulse>();
@@ -451,7 +464,6 @@ static int trace_common(rvb_ctx * ctx, const float * mics, const float * sources
     while (key_bits < 32 && (1ull << key_bits) < ctx->scene.ntris) ++key_bits;
     // The grouping only has to bring neighbouring triangles together: the top 16 bits of the leaf position are two
     // onesweep passes instead of three (C2, 17 key bits: grouping 0.66 -> 0.51 ms beside image_kernel, shadow_kernel +0.02 ms).
-    static const int group_bits = getenv("RVB_SHADOW_SORT_BITS") ? atoi(getenv("RVB_SHADOW_SORT_BITS")) : 16;
     if (sort_records && nrecords && nrecords < (1ull << 32) && ctx->scene.ntris) {
         RVB_HIP(ctx, ctx->sort_keys.ensure(nrecords * 4));
         RVB_HIP(ctx, ctx->sort_scratch.ensure(nrecords * 4));
@@ -468,7 +480,8 @@ static int trace_common(rvb_ctx * ctx, const float * mics, const float * sources
     a.stack_entries = ctx->stack_need;
     a.lds_surfaces = rvb_lds_surfaces(ctx->stack_need, ctx->nsurfaces);
     a.scene_nodes = (uint32_t) ctx->nnodes;
-    a.path_lanes = rvb_path_lanes_for(nrays, ctx->concurrent_traces);
+    // (rays_in_flight: what a group launch carries in all; 0 = this trace alone, times the caller's hint)
+    a.path_lanes = rays_in_flight ? rvb_path_lanes_for(rays_in_flight, 1) : rvb_path_lanes_for(nrays, ctx->concurrent_traces);
     a.ray_offset = ray_offset;
     for (int i = 0; i < 3; ++i) { a.mic[i] = mic[i]; a.source[i] = source[i]; ctx->mic[i] = mic[i]; }
     for (int i = 0; i < 8; ++i) a.air[i] = air_coefficient[i];
@@ -486,9 +499,19 @@ static int trace_common(rvb_ctx * ctx, const float * mics, const float * sources
     }
 
     ctx->reset_timings();
-    ctx->begin_timing(a.path_lanes == 2 ? "path_pair_kernel" : "path_kernel");
-    rvb_launch_path(a, ctx->stream);
-    ctx->end_timing();
+    plan.npairs = npairs;
+    plan.nrays = nrays;
+    plan.nreflections = nreflections;
+    plan.key_bits = key_bits;
+    return RVB_OK;
+}
+
+static int trace_finish(rvb_ctx * ctx, TracePlan & plan, const float * mics)
+{
+    TraceArgs & a = plan.a;
+    const uint64_t npairs = plan.npairs, nrays = plan.nrays, nreflections = plan.nreflections;
+    const int key_bits = plan.key_bits;
+    static const int group_bits = getenv("RVB_SHADOW_SORT_BITS") ? atoi(getenv("RVB_SHADOW_SORT_BITS")) : 16;
     // image_kernel and the record grouping both depend on path_kernel only: the first (latency-bound) runs on the
     // side stream beside the second (bandwidth-bound); shadow_kernel, which rewrites the records image_kernel
     // reads, waits for both.
@@ -532,6 +555,76 @@ static int trace_common(rvb_ctx * ctx, const float * mics, const float * sources
     ctx->traced_rays = nrays;
     ctx->ir_pair = 0;
     ctx->pair_mics_host.assign(mics, mics + 3 * npairs);
+    return RVB_OK;
+}
+
+static int trace_common(rvb_ctx * ctx, const float * mics, const float * sources, uint64_t npairs, uint64_t nreflections,
+                        const float air_coefficient[8], uint64_t ray_offset)
+{
+    TracePlan plan;
+    int rc = trace_prepare(ctx, mics, sources, npairs, nreflections, air_coefficient, ray_offset, 0, plan);
+    if (rc != RVB_OK) return rc;
+    ctx->begin_timing(plan.a.path_lanes == 2 ? "path_pair_kernel" : "path_kernel");
+    rvb_launch_path(plan.a, ctx->stream);
+    ctx->end_timing();
+    return trace_finish(ctx, plan, mics);
+}
+
+int rvb_trace_group(rvb_ctx ** ctxs, uint64_t count, const float * mics, const float * sources, uint64_t nreflections,
+                    const float air_coefficient[8], const uint64_t * ray_offsets)
+{
+    if (!ctxs || count == 0 || count > RVB_MAX_GROUP) return RVB_ERR_INVALID;
+    for (uint64_t i = 0; i < count; ++i)
+        if (!ctxs[i]) return RVB_ERR_INVALID;
+    if (!mics || !sources || !air_coefficient) return fail(ctxs[0], RVB_ERR_INVALID, "rvb_trace_group: null argument");
+    for (uint64_t i = 0; i < count; ++i)
+        for (uint64_t j = 0; j < i; ++j)
+            if (ctxs[i] == ctxs[j]) return fail(ctxs[0], RVB_ERR_INVALID, "rvb_trace_group: a context is listed twice");
+    uint64_t total_rays = 0;
+    for (uint64_t i = 0; i < count; ++i) total_rays += ctxs[i]->nrays;
+    TracePlan plans[RVB_MAX_GROUP];
+    for (uint64_t i = 0; i < count; ++i) {
+        const int rc = trace_prepare(ctxs[i], mics + 3 * i, sources + 3 * i, 1, nreflections, air_coefficient, ray_offsets ? ray_offsets[i] : 0,
+                                     total_rays, plans[i]);
+        if (rc != RVB_OK) return rc;
+    }
+    // one launch for all of them when they can share a kernel: two lanes per ray, one device, one LDS layout
+    bool fused = count > 1 && plans[0].a.path_lanes == 2;
+    for (uint64_t i = 1; i < count && fused; ++i)
+        fused = ctxs[i]->device == ctxs[0]->device && plans[i].a.path_lanes == 2 && plans[i].a.stack_entries == plans[0].a.stack_entries
+                && plans[i].a.lds_surfaces == plans[0].a.lds_surfaces;
+    for (uint64_t i = 0; i < count && fused; ++i) fused = plans[i].nrays > 0;
+    if (fused) {
+        rvb_ctx * lead = ctxs[0];
+        RVB_BIND(lead);
+        for (uint64_t i = 1; i < count; ++i) {                      // the others' fills come first
+            RVB_HIP(ctxs[i], hipEventRecord(ctxs[i]->prep_done, ctxs[i]->stream));
+            RVB_HIP(lead, hipStreamWaitEvent(lead->stream, ctxs[i]->prep_done, 0));
+        }
+        TraceArgs args[RVB_MAX_GROUP];
+        for (uint64_t i = 0; i < count; ++i) args[i] = plans[i].a;
+        lead->begin_timing("path_pair_kernel");
+        rvb_launch_path_group(args, (uint32_t) count, lead->stream);
+        lead->end_timing();
+        RVB_HIP(lead, hipEventRecord(lead->group_done, lead->stream));
+        for (uint64_t i = 1; i < count; ++i) {
+            ctxs[i]->begin_timing("path_pair_kernel");              // (elapsed: from this stream's arrival to the end of the group's kernel)
+            RVB_HIP(ctxs[i], hipStreamWaitEvent(ctxs[i]->stream, lead->group_done, 0));
+            ctxs[i]->end_timing();
+        }
+    } else {
+        for (uint64_t i = 0; i < count; ++i) {
+            RVB_BIND(ctxs[i]);
+            ctxs[i]->begin_timing(plans[i].a.path_lanes == 2 ? "path_pair_kernel" : "path_kernel");
+            rvb_launch_path(plans[i].a, ctxs[i]->stream);
+            ctxs[i]->end_timing();
+        }
+    }
+    for (uint64_t i = 0; i < count; ++i) {
+        RVB_BIND(ctxs[i]);
+        const int rc = trace_finish(ctxs[i], plans[i], mics + 3 * i);
+        if (rc != RVB_OK) return rc;
+    }
     return RVB_OK;
 }
 

@@ -57,6 +57,9 @@ void rvb_launch_path(const TraceArgs & a, hipStream_t s);
 uint32_t rvb_lds_surfaces(uint32_t stack_entries, uint64_t nsurfaces);
 // lanes per ray for a launch of `nrays` rays when the caller keeps `concurrent` such traces in flight on the device
 uint32_t rvb_path_lanes_for(uint64_t nrays, uint32_t concurrent);
+// the two-lane path kernel for up to RVB_MAX_GROUP traces (contexts) in ONE launch: their waves are dispatched and scheduled together
+#define RVB_MAX_GROUP 4
+void rvb_launch_path_group(const TraceArgs * traces, uint32_t count, hipStream_t s);
 uint32_t rvb_shadow_lanes();        // lanes per record in the shadow kernel: 2 (shadow_pair_kernel) unless RVB_SHADOW_LANES=4
 // Phase C: one lane per (ray, bounce < 9): image-source validation (kernel.cpp:379-457) + slot 0.
 void rvb_launch_images(const TraceArgs & a, hipStream_t s);

@@ -968,11 +968,11 @@ __global__ __launch_bounds__(WAVE, WAVES) void path_kernel(TraceArgs a)
 #define RVB_PAIR_WAVES 4            // waves per SIMD the register budget allows (100 k rays are 3.05 waves per SIMD)
 #endif
 template <bool SURF_LDS>
-__global__ __launch_bounds__(WAVE, RVB_PAIR_WAVES) void path_pair_kernel(TraceArgs a)
+__device__ __forceinline__ void path_pair_body(const TraceArgs & a, const uint32_t block)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t stack_lds[];   // [stack_entries][PAIRS_PER_BLOCK]
     const uint32_t q = threadIdx.x >> 1;
-    const uint64_t ray = (uint64_t) blockIdx.x * PAIRS_PER_BLOCK + q;
+    const uint64_t ray = (uint64_t) block * PAIRS_PER_BLOCK + q;
     const lds_float4_ptr surf_lds = stage_surfaces(a, stack_lds + a.stack_entries * PAIRS_PER_BLOCK);
 #if RVB_LDS_NODES
     lds_float4_ptr lds_nodes;
@@ -1014,6 +1014,29 @@ __global__ __launch_bounds__(WAVE, RVB_PAIR_WAVES) void path_pair_kernel(TraceAr
     }
     if (job.c == 0)
         atomicAdd(a.executed, (unsigned long long) job.index);
+}
+
+template <bool SURF_LDS>
+__global__ __launch_bounds__(WAVE, RVB_PAIR_WAVES) void path_pair_kernel(TraceArgs a)
+{
+    path_pair_body<SURF_LDS>(a, blockIdx.x);
+}
+
+// Several traces (contexts: their own rays, buffers, source and microphone) in ONE launch.  Two path kernels launched side by side
+// are not scheduled alike — the first one's waves are older and issue first, the second runs on alone at half the occupancy (4.9 and
+// 7.9 ms at workload C2) — whereas the waves of one launch advance together.  first_block[k] = first workgroup of trace k.
+struct TraceGroup {
+    uint32_t count;
+    uint32_t first_block[RVB_MAX_GROUP + 1];
+    TraceArgs trace[RVB_MAX_GROUP];
+};
+template <bool SURF_LDS>
+__global__ __launch_bounds__(WAVE, RVB_PAIR_WAVES) void path_pair_group_kernel(TraceGroup g)
+{
+    uint32_t which = 0;
+    for (uint32_t k = 1; k < g.count; ++k)
+        which += blockIdx.x >= g.first_block[k] ? 1u : 0u;
+    path_pair_body<SURF_LDS>(g.trace[which], blockIdx.x - g.first_block[which]);
 }
 
 // reference kernel.cpp:243-265 (add_image) for a known-valid slot
@@ -1465,6 +1488,25 @@ void rvb_launch_path(const TraceArgs & a, hipStream_t s)
         if (seven) hipLaunchKernelGGL((path_kernel<false, 7>), dim3(blocks), dim3(WAVE), quad_kernel_lds_bytes(a), s, a);
         else hipLaunchKernelGGL((path_kernel<false, 8>), dim3(blocks), dim3(WAVE), quad_kernel_lds_bytes(a), s, a);
     }
+}
+
+void rvb_launch_path_group(const TraceArgs * traces, uint32_t count, hipStream_t s)
+{
+    TraceGroup g;
+    g.count = count;
+    uint32_t blocks = 0;
+    for (uint32_t k = 0; k < count; ++k) {
+        g.first_block[k] = blocks;
+        g.trace[k] = traces[k];
+        blocks += (uint32_t) ((traces[k].nrays + PAIRS_PER_BLOCK - 1) / PAIRS_PER_BLOCK);
+    }
+    for (uint32_t k = count; k <= RVB_MAX_GROUP; ++k) g.first_block[k] = blocks;
+    for (uint32_t k = count; k < RVB_MAX_GROUP; ++k) g.trace[k] = traces[0];
+    // (the caller checked: every trace has the same stack depth and the same number of surfaces staged in LDS)
+    const TraceArgs & a = traces[0];
+    const size_t lds = a.stack_entries * PAIRS_PER_BLOCK * sizeof(uint32_t) + (size_t) a.lds_surfaces * sizeof(rvb_surface) + RVB_LDS_NODES * 64u;
+    if (a.lds_surfaces) hipLaunchKernelGGL(path_pair_group_kernel<true>, dim3(blocks), dim3(WAVE), lds, s, g);
+    else hipLaunchKernelGGL(path_pair_group_kernel<false>, dim3(blocks), dim3(WAVE), lds, s, g);
 }
 
 void rvb_launch_images(const TraceArgs & a, hipStream_t s)

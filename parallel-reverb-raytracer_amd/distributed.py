@@ -197,6 +197,7 @@ class IrPipeline:
         self.tracers = list(tracers)
         self.next_slot = 0
         self.begun = [False] * len(self.tracers)
+        self.fuse_groups = __import__("os").environ.get("RVB_PIPELINE_FUSE", "1") != "0"       # one path-kernel launch per group
         # the traces of a group run side by side (run_jobs): tell the contexts, so that the path kernel is sized for the rays in flight
         for t in self.tracers:
             if hasattr(t, "set_concurrent_traces"):
@@ -226,6 +227,20 @@ class IrPipeline:
             begin_ir(self.tracers[slot], *trace_args, ray_offset=ir_kwargs.get("ray_offset", 0))
             self.begun[slot] = True
 
+        def begin_group(ks):
+            """The traces of a group in ONE path-kernel launch (Context.trace_group) when the contexts offer it and the jobs agree in
+            reflection count and air coefficients; one after the other otherwise."""
+            tracers = [self.tracers[(first + k) % n] for k in ks]
+            same = all(jobs[k][0][2] == jobs[ks[0]][0][2] and tuple(jobs[k][0][3]) == tuple(jobs[ks[0]][0][3]) for k in ks)
+            if len(ks) > 1 and same and all(hasattr(t, "trace_group") for t in tracers) and self.fuse_groups:
+                tracers[0].trace_group(tracers, [jobs[k][0][0] for k in ks], [jobs[k][0][1] for k in ks], jobs[ks[0]][0][2], jobs[ks[0]][0][3],
+                                       [jobs[k][1].get("ray_offset", 0) for k in ks])
+                for k in ks:
+                    self.begun[(first + k) % n] = True
+            else:
+                for k in ks:
+                    begin(k)
+
         # Default schedule: jobs are enqueued in GROUPS of `group` traces (their path kernels then run side by side: more waves
         # per SIMD, see DESIGN.md "rays per launch"), and group j+1 is enqueued before group j is finished.  group =
         # len(tracers) // 2; two contexts: group 1 = the plain alternation.  RVB_PIPELINE_AHEAD=k instead keeps k traces
@@ -236,8 +251,13 @@ class IrPipeline:
 
         def begin_upto(k):
             while begun_upto[0] < min(k, len(jobs)):
-                begin(begun_upto[0])
-                begun_upto[0] += 1
+                if n > 1 and ahead <= 0 and group > 1:               # (group boundaries: begun_upto is a multiple of group here)
+                    ks = list(range(begun_upto[0], min(begun_upto[0] + group, k, len(jobs))))
+                    begin_group(ks)
+                    begun_upto[0] += len(ks)
+                else:
+                    begin(begun_upto[0])
+                    begun_upto[0] += 1
 
         begin_upto(group if ahead <= 0 else 1 + ahead)
         if n > 1 and ahead <= 0:

@@ -467,3 +467,50 @@ def test_pairs_in_one_launch_equal_pairs_one_by_one(ctx):
         for a, b in zip(ir, ir_alone):
             assert a.shape == b.shape and np.array_equal(a, b)
     assert any(a[4][0].any() for a in alone)
+
+
+def test_trace_group_one_launch_for_three_contexts_equals_three_traces(ctx):
+    """rvb_trace_group: the path kernels of several contexts in ONE launch (what distributed.IrPipeline does with the traces of a
+    group).  Three contexts with their own ray sets (one of them ragged: not a multiple of the 32 rays per wave), sources,
+    microphones and ray offsets; the raw diffuse impulses, the image-source candidates, the direct path and an exact-mode IR of each
+    must be the bytes the same context produces with rvb_trace."""
+    from parallel_reverb_raytracer_amd import capi
+    scene, info = scenes.cathedral(20000)
+    counts, nrefl = [90000, 70001, 60000], 6                       # 220 001 rays in all: enough for the two-lane kernel
+    mics = [info["mic"], (10.0, 2.0, 1.0), (-5.0, 1.5, -2.0)]
+    sources = [info["source"], (-12.0, 1.7, 0.5), (6.0, 2.5, 3.0)]
+    offsets = [0, 90000, 1 << 33]
+    others = [capi.Context(0), capi.Context(0)]
+    contexts = [ctx] + others
+    try:
+        want = []
+        for c, n, m, s, off in zip(contexts, counts, mics, sources, offsets):
+            c.set_scene(scene)
+            c.set_directions(scenes.sphere_directions(n, seed=n))
+            c.trace(m, s, nrefl, AIR_COEFFICIENTS, ray_offset=off)
+            images = capi.merge_images(c.get_image_candidates(), c.get_direct(), False)
+            c.ir_configure_speakers(m, [(-1, 0, -1), (1, 0, -1)], [0.5, 0.5], capi.IR_ALL, images)
+            want.append((c.get_raw_diffuse().tobytes(), c.get_image_candidates().tobytes(), c.get_direct().tobytes(),
+                         c.ir_download(True, 44100.0, capi.IR_EXACT)))
+        capi.Context.trace_group(contexts, mics, sources, nrefl, AIR_COEFFICIENTS, offsets)
+        for c, m, (diffuse, cands, direct, ir) in zip(contexts, mics, want):
+            assert "path_pair_kernel" in dict(c.last_timings())
+            assert c.get_raw_diffuse().tobytes() == diffuse
+            assert c.get_image_candidates().tobytes() == cands and c.get_direct().tobytes() == direct
+            images = capi.merge_images(c.get_image_candidates(), c.get_direct(), False)
+            c.ir_configure_speakers(m, [(-1, 0, -1), (1, 0, -1)], [0.5, 0.5], capi.IR_ALL, images)
+            again = c.ir_download(True, 44100.0, capi.IR_EXACT)
+            assert again.shape == ir.shape and np.array_equal(again, ir)
+        # a small group falls back to one launch per context (four lanes per ray): same results again
+        for c in contexts:
+            c.set_directions(scenes.sphere_directions(777, seed=5))
+        small = []
+        for c, m, s in zip(contexts, mics, sources):
+            c.trace(m, s, 12, AIR_COEFFICIENTS)
+            small.append(c.get_raw_diffuse().tobytes())
+        capi.Context.trace_group(contexts, mics, sources, 12, AIR_COEFFICIENTS)
+        for c, b in zip(contexts, small):
+            assert c.get_raw_diffuse().tobytes() == b
+    finally:
+        for c in others:
+            c.close()
