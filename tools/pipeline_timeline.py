@@ -8,7 +8,7 @@ import csv
 import sys
 from collections import Counter, defaultdict
 
-NAMES = ["path_pair_kernel", "path_kernel", "shadow_pair_kernel", "shadow_kernel", "image_kernel", "ordered_sum_kernel", "bin_keys_kernel",
+NAMES = ["path_pair_group_kernel", "path_pair_kernel", "path_kernel", "shadow_pair_kernel", "shadow_kernel", "image_kernel", "ordered_sum_kernel", "bin_keys_kernel",
          "bin_starts_kernel", "radix_sort_onesweep_iteration", "radix_sort_onesweep_global_offsets", "histogram_fast_kernel",
          "histogram_transpose_kernel", "time_range_kernel", "fillBuffer", "copyBuffer"]
 
@@ -24,10 +24,10 @@ def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 16
     events = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r["Stream_Id"]) for r in rows)
-    paths = [e for e in events if e[2] in ("path_pair_kernel", "path_kernel")]
-    region = paths[-steps:]
+    paths = [e for e in events if e[2] in ("path_pair_group_kernel", "path_pair_kernel", "path_kernel")]
+    region = paths[-(steps // 2 if paths and paths[-1][2] == "path_pair_group_kernel" else steps):]      # (a group kernel carries two traces)
     t0, t1 = region[0][0], max(e[1] for e in events)
-    print("timed region: %d path kernels, %.2f ms = %.3f ms per IR" % (len(region), (t1 - t0) / 1e6, (t1 - t0) / 1e6 / len(region)))
+    print("timed region: %d path kernels for %d IRs, %.2f ms = %.3f ms per IR" % (len(region), steps, (t1 - t0) / 1e6, (t1 - t0) / 1e6 / steps))
     print("path kernels (start ms, duration ms, stream):")
     for s, e, n, st in region:
         print("  %8.2f %6.2f  stream %s  %s" % ((s - t0) / 1e6, (e - s) / 1e6, st, n))
@@ -43,7 +43,7 @@ def main():
     by_paths, idle = Counter(), 0
     for t, d, n in points:
         if t > last:
-            k = running["path_pair_kernel"] + running["path_kernel"]
+            k = running["path_pair_group_kernel"] + running["path_pair_kernel"] + running["path_kernel"]
             by_paths[min(k, 3)] += t - last
             if sum(running.values()) == 0:
                 idle += t - last

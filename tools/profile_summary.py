@@ -10,7 +10,7 @@ import sys
 
 tag = sys.argv[1]
 out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
-SHORT = ["path_kernel", "path_pair_kernel", "image_kernel", "shadow_kernel", "shadow_pair_kernel", "histogram_fast_kernel", "histogram_transpose_kernel", "attenuate_kernel",
+SHORT = ["path_kernel", "path_pair_group_kernel", "path_pair_kernel", "image_kernel", "shadow_kernel", "shadow_pair_kernel", "histogram_fast_kernel", "histogram_transpose_kernel", "attenuate_kernel",
          "time_range_kernel", "bin_keys_kernel", "ordered_sum_kernel", "radix_sort_onesweep_iteration", "radix_sort_onesweep_global_offsets"]
 
 # VALU issue model: dynamic instruction mix (per-class PMC counters) x measured issue cost per class (tools/inst_probe.hip at
@@ -114,4 +114,4 @@ json.dump({"irs_in_command": irs, "valu_wave_instructions_per_ir": valu_per_ir, 
                    "128-B requests as 64 B: MI355X_MICROARCH.md HBM section; upper bound for gather-heavy kernels)" % tag,
            "kernels": pmc}, open(os.path.join(out, tag + "_pmc.json"), "w"), indent=1)
 print(json.dumps({k: {c: round(v, 4) if isinstance(v, float) else v for c, v in d.items() if not c.startswith("SQ_INSTS_V")} for k, d in pmc.items()
-                  if k in ("path_kernel", "path_pair_kernel", "shadow_kernel", "shadow_pair_kernel")}, indent=1))
+                  if k in ("path_kernel", "path_pair_kernel", "path_pair_group_kernel", "shadow_kernel", "shadow_pair_kernel")}, indent=1))
