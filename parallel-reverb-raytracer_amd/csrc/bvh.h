@@ -28,7 +28,9 @@
 #define RVB_BVH_EMPTY 0xFFFFFFFFu
 #define RVB_BVH_LEAF 0x80000000u
 #define RVB_BVH_NODE_SHIFT 6         // node references are BYTE offsets (index * 64): one 32-bit add forms the load address
+#ifndef RVB_BVH_MAX_LEAF
 #define RVB_BVH_MAX_LEAF 4
+#endif
 #define RVB_BVH_STACK 64            // per-lane traversal stack entries (LDS)
 
 struct BvhChild {                   // 16 B = one 16-byte load
