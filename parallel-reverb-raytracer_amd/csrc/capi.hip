@@ -399,6 +399,7 @@ static int trace_prepare(rvb_ctx * ctx, const float * mics, const float * source
         return fail(ctx, RVB_ERR_CAPACITY, "rvb_trace: too many reflections or rays for one context");
     const float * mic = mics, * source = sources;
     RVB_BIND(ctx);
+    ctx->traced = false;                              // (until trace_finish: a failure below must not leave the last trace's results half reset)
     const uint64_t nrays = ctx->nrays * npairs;       // rays of this launch
     const size_t imp_bytes = (size_t) nrays * nreflections * sizeof(rvb_impulse);
     const size_t early_bytes = (size_t) nrays * 9 * sizeof(uint32_t);
