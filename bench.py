@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """bench.py — ray-bounces/s and IR-generation wall-clock of the hot path on MI355X.
 
-One step = one full impulse-response generation for one batch of rays, everything resident in HBM:
+One step = one full impulse-response generation for one batch of rays, inputs resident in HBM, result ON THE HOST
+("until [channels][8][nbins] is on the host"):
     trace (path + image-source + shadow kernels)  ->  image-source candidates to the host, de-dup
     ->  fused attenuate + predelay + time-binning into [channels][8][nbins]  (-> RCCL sum over ranks)
+    ->  the finished histogram copied to pinned host memory on a side stream (an IR counts once it is there)
 Workload at N=1 = BASELINE.json configs[1]: cathedral stand-in (~75k triangles; Sibenik itself is
 not available offline), 100k rays x 128 bounces x 8 bands, two cardioid speakers, 44.1 kHz,
 trim_predelay.  With N>1 ranks (one process per GPU, torch.distributed/RCCL) the workload is configs[2]'s
@@ -14,6 +16,10 @@ data-path collective.
 The binning runs in EXACT mode by default: every rank's histogram is the reference's serial float sum over its
 impulses, bit for bit (tests/test_gpu_fullsize.py checks it against the oracle chain at this very size).  The
 float-atomic mode is reported beside it (`fast_mode`) with its measured distance from the exact histogram.
+
+`python bench.py --gpus N` with N > 1 and no torchrun environment starts its N rank processes itself (child processes of a
+parent that never touches the GPU) and relays rank 0's line; the driver's own `python -m torch.distributed.run ... bench.py
+--gpus N` form is taken as it comes.
 
 Prints ONE JSON line on rank 0.
 """
@@ -42,8 +48,8 @@ BYTES_PER_BOUNCE = 69.75          # 64 B Impulse per bounce + 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--warmup", type=int, default=4)
+    p.add_argument("--steps", type=int, default=200, help="timed impulse responses (200 = about a second: long enough for a stable number and for the driver's samplers)")
+    p.add_argument("--warmup", type=int, default=8)
     p.add_argument("--rays", type=int, default=0, help="rays per GPU (default: 100000 on one GPU = config C2, 125000 per GPU otherwise = config C3's share)")
     p.add_argument("--reflections", type=int, default=128)
     p.add_argument("--triangles", type=int, default=75000)
@@ -57,6 +63,8 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     p.add_argument("--rehearse-collectives", action="store_true",
                    help="with one rank: create the process group anyway and run every collective of the multi-GPU path on it")
+    p.add_argument("--no-host-copy", action="store_true", help="leave the finished histograms in HBM (the round-1/2 metric; diagnostic)")
+    p.add_argument("--master-port", type=int, default=0, help="rendezvous port when bench.py starts its own ranks (0: a free one)")
     p.add_argument("--contexts", type=int, default=4, help="contexts per GPU that take turns (4: the traces of IRs i+2, i+3 are enqueued "
                    "together, beside the grouping / binning / host stages of IRs i, i+1; 2: plain alternation; 1: strictly one IR at a time)")
     return p.parse_args()
@@ -112,8 +120,49 @@ def fast_vs_exact(fast, exact):
             "band_bins": int(err.numel()), "band_bins_differing": int((err > 0).sum())}
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` (N > 1) outside torchrun: start the N ranks as CHILD processes — this parent has not made a
+    single GPU call (nothing here imports a HIP runtime before this point) and only relays rank 0's JSON line and the exit
+    code.  One process per GPU, rendezvous on 127.0.0.1."""
+    import socket
+    import subprocess
+    port = args.master_port
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["RVB_BENCH_SELF_LAUNCHED"] = "1"
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env)
+    line = None
+    for raw in proc.stdout:                               # rank 0's one JSON line (everything else the ranks print goes to stderr)
+        text = raw.decode(errors="replace")
+        if text.lstrip().startswith("{") and '"metric"' in text:
+            line = text
+        else:
+            sys.stderr.write(text)
+    rc = proc.wait()
+    if rc == 0 and line is None:
+        print("bench.py: the ranks exited without a result line", file=sys.stderr)
+        rc = 1
+    if line is not None and rc == 0:
+        got = json.loads(line).get("n_gpus")
+        if got != args.gpus:
+            print("bench.py: %d ranks took part, --gpus %d was asked for" % (got, args.gpus), file=sys.stderr)
+            rc = 1
+    if line is not None and rc == 0:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    sys.exit(rc)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)                                # does not return
     # Rank 0 owes the driver ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner to
     # stdout when a communicator is created, gloo its connection notes), so everything that is not the result goes to stderr:
     # file descriptor 1 is pointed at stderr for the whole run and the JSON line is written to the saved original.
@@ -138,8 +187,11 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend)
-    if world != args.gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    if world != args.gpus or (grouped and dist.get_world_size() != world):
+        # a line that says n_gpus N must come from N ranks: refuse anything else (the driver computes scaling from it)
+        print("bench.py: --gpus %d but %d rank(s) in the process group (WORLD_SIZE %d)"
+              % (args.gpus, dist.get_world_size() if grouped else 1, world), file=sys.stderr)
+        sys.exit(3)
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
@@ -178,8 +230,28 @@ def main():
                     mode=mode if ir_mode is None else ir_mode,
                     rank=rank, world=world, ray_offset=first_ray, device=device, on_stage=on_stage, collectives=grouped)
 
+    # an impulse response is generated once [channels][8][nbins] is ON THE HOST.  Every finished histogram is
+    # copied to pinned host memory on a side stream (54 MB at C2, about 1 ms of PCIe beside the next IRs' kernels); the timed
+    # region ends when the last copy has landed (fence() waits for every stream of the device).
+    to_host = not args.no_host_copy
+    copy_stream = torch.cuda.Stream(device) if to_host else None
+    host_ring = []
+
     def keep(hist, info, _tracer):
         state.update(hist=hist, nbins=info["nbins"], images=info["images"], predelay=info["predelay"])
+        if not to_host:
+            return
+        if not host_ring or host_ring[0].shape != hist.shape:
+            host_ring[:] = [torch.empty(hist.shape, dtype=hist.dtype, pin_memory=True) for _ in range(4)]
+            state["slot"] = 0
+        buf = host_ring[state["slot"] % len(host_ring)]
+        state["slot"] += 1
+        # (the binning ran on the context's stream and the host has waited for it; the all-reduce, if any, is ordered on torch's current stream)
+        copy_stream.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(copy_stream):
+            buf.copy_(hist, non_blocking=True)
+        hist.record_stream(copy_stream)                    # the allocator must not hand the block out again before the copy has read it
+        state["host"] = buf
 
     def fence():
         for c in contexts:
@@ -242,6 +314,25 @@ def main():
     bounces_per_step = world * rays_per_gpu * nrefl
     value = bounces_per_step / (elapsed / args.steps)
     executed = ctx.executed_bounces()
+
+    # What the timed region produced must be what one IR generated strictly alone produces: the last histogram of the pipelined,
+    # fused (two traces per path-kernel launch) region — as it landed on the host — against a solo IR of the same arguments.
+    # Exact mode on one rank: bit for bit (the serial-order sum has one value).  Several ranks add their serial sums with an
+    # all-reduce, float atomics have no fixed order: there the bar is the stated tolerance, 1e-5 of each band's largest value.
+    timed_hist = (state["host"] if to_host else state["hist"].cpu()).clone()
+    solo_hist, _ = distributed.generate_ir(ctx, *trace_args, **ir_kwargs(None))
+    fence()
+    solo_host = solo_hist.cpu()
+    bit_equal = bool(torch.equal(timed_hist, solo_host))
+    band_max = solo_host.double().abs().amax(dim=2, keepdim=True).clamp_min(1e-300)
+    worst = float(((timed_hist.double() - solo_host.double()).abs() / band_max).max()) if timed_hist.shape == solo_host.shape else float("inf")
+    must_be_equal = args.mode == "exact" and world == 1
+    timed_check = {"last_timed_histogram_equals_solo_ir": bit_equal, "max_abs_err_over_band_max": worst,
+                   "required": "bit-equal" if must_be_equal else "<= 1e-5 of each band's maximum"}
+    if (must_be_equal and not bit_equal) or worst > 1e-5 or not bool(solo_host.any()):
+        print("bench.py: the timed region's histogram differs from a solo IR: %s" % json.dumps(timed_check), file=sys.stderr)
+        sys.exit(4)
+    del solo_hist, solo_host, timed_hist
 
     # the other binning mode through the same timed pipeline, and how far the float-atomic histogram is from the exact one
     other_mode, comparison = None, None
@@ -380,7 +471,10 @@ def main():
                                    % (scene[0].shape[0], rays_per_gpu, nrefl, sr, args.mode,
                                       "" if world == 1 else " (BASELINE configs[2]'s shape: %d rays over %d GPUs)" % (rays_per_gpu * world, world)),
                        "triangles": int(scene[0].shape[0]), "rays_per_gpu": rays_per_gpu, "reflections": nrefl,
-                       "histogram_mode": args.mode + (": every rank's histogram is the reference's serial float sum over its impulses, bit for bit"
+                       "histogram_mode": args.mode + ((": the reference's serial float sum over all impulses, bit for bit" if world == 1 else
+                                                       ": every rank's histogram is the serial float sum over ITS impulses; the ranks' histograms are then "
+                                                       "added by one all-reduce, so the result is within 1e-5 of each band's maximum of the single-GPU "
+                                                       "serial sum, not bit-equal to it (the bit-equal chain over devices is rvb_multi_*, csrc/multi.hip)")
                                                       if args.mode == "exact" else ": float atomics, order-dependent in the last bits"),
                        "histogram_seconds": state["nbins"] / sr,
                        "sharding": "ray-range shards, replicated scene, one all-reduce(sum) of [2][8][nbins] histograms",
@@ -389,7 +483,10 @@ def main():
             "lanes_per_ray": {"path_kernel_in_timed_region": 2 if "path_pair_kernel" in avg else 4,
                               "path_kernel_one_ir_alone": 4 if "path_kernel" in solo else 2, "shadow_kernel": 2 if "shadow_pair_kernel" in solo else 4,
                               "rule": "rvb_path_lanes_for (csrc/trace_kernels.hip): two lanes per ray when rays per launch x traces in flight >= 196 608"},
-            "ir_gen_wall_ms": solo_latency_ms, "ir_gen_to_host_ms": to_host_latency_ms, "contexts_per_gpu": len(contexts),
+            # one IR strictly alone, wall clock incl. the Python host path: until [channels][8][nbins] is on the host /
+            # with the histogram left in HBM
+            "ir_gen_wall_ms": to_host_latency_ms, "ir_gen_to_host_ms": to_host_latency_ms, "ir_gen_wall_ms_histogram_in_hbm": solo_latency_ms,
+            "result_on_host_in_timed_region": to_host, "timed_region_check": timed_check, "contexts_per_gpu": len(contexts),
             "fast_mode" if args.mode == "exact" else "exact_mode": other_mode, "fast_vs_exact": comparison, "api_flow": api_flow,
             "trace_only_ray_bounces_per_sec": (nrays * nrefl) / (trace_ms * 1e-3) if trace_ms else None,
             "executed_bounces_rank0": int(executed), "nominal_bounces_rank0": nrays * nrefl,

@@ -155,7 +155,9 @@ int rvb_attenuate_hrtf_device(rvb_ctx * ctx, const float mic[3], const void * d_
 
 /* ---- time binning, materialised: replaces flattenImpulses (rayverb.cpp:48-77) for one channel.
  * Bit-exact with the reference's serial summation order.  out is [8][*nbins].  Called with out == NULL it reports *nbins;
- * a following call with the same (in, n, sample_rate) finds the uploaded array and its keys still on the device. */
+ * a following call with the same (in, n, sample_rate) finds the uploaded array and its keys still on the device, unless another
+ * call on this context has used the sort buffers in between (then the fill uploads again).  PRECONDITION of that pair: the
+ * caller does not change in[0 .. n) between the size query and the fill — the fill does not read the host array again. */
 int rvb_flatten(rvb_ctx * ctx, const rvb_attenuated_impulse * in, uint64_t n, float sample_rate,
                 float * out, uint64_t capacity_bins, uint64_t * nbins);
 

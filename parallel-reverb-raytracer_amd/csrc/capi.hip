@@ -89,6 +89,7 @@ struct rvb_ctx {
     AttenuationModel model;
     int which = RVB_IR_ALL;
     DevBuf images, hrtf_table, acc, keys_a, keys_b, vals_a, vals_b, sort_temp, scratch_in, scratch_out, hist, bin_starts;
+    DevBuf flat_in;                              // rvb_flatten's upload: a buffer of its own, so that no other entry point overwrites it between a size query and the fill
     DevBuf own_sort_temp, own_sort_keys, own_sort_values;      // csrc/radix_sort.hip: tile counters, the intermediate (key, value) pair
     uint64_t nimages = 0;
     std::vector<rvb_impulse> images_host;
@@ -96,7 +97,9 @@ struct rvb_ctx {
     // staged host copies (rvb_copy_to_host / rvb_copy_to_device): per worker thread two pinned bounce buffers and a stream
     struct CopyLane { void * pinned[2] = {nullptr, nullptr}; hipStream_t stream = nullptr; hipEvent_t done[2] = {nullptr, nullptr}; };
     std::vector<CopyLane> copy_lanes;
-    // rvb_flatten remembers what it uploaded for a size query, so that the fill that follows does not upload and key it again
+    // rvb_flatten remembers what it uploaded for a size query, so that the fill that follows does not upload and key it again.
+    // The array sits in flat_in (written by rvb_flatten only), its keys in keys_a / vals_a: every other writer of those two
+    // (rvb_ir_accumulate in exact mode, rvb_flatten_device) clears flat_host, and so does a reallocation of the sort buffers.
     const void * flat_host = nullptr;
     uint64_t flat_n = 0, flat_bins = 0;
     float flat_rate = 0.0f;
@@ -231,7 +234,7 @@ void rvb_destroy(rvb_ctx * ctx)
     if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
     for (DevBuf * b : {&ctx->nodes, &ctx->tris, &ctx->shade, &ctx->corners, &ctx->surfaces, &ctx->leafpos, &ctx->sort_keys, &ctx->sort_scratch, &ctx->sort_order, &ctx->group_temp, &ctx->directions_own, &ctx->impulses,
                        &ctx->early, &ctx->candidates, &ctx->small, &ctx->stamps, &ctx->images, &ctx->hrtf_table, &ctx->acc, &ctx->keys_a,
-                       &ctx->keys_b, &ctx->vals_a, &ctx->vals_b, &ctx->sort_temp, &ctx->scratch_in, &ctx->scratch_out, &ctx->hist, &ctx->bin_starts, &ctx->own_sort_temp, &ctx->own_sort_keys, &ctx->own_sort_values,
+                       &ctx->keys_b, &ctx->vals_a, &ctx->vals_b, &ctx->sort_temp, &ctx->scratch_in, &ctx->scratch_out, &ctx->flat_in, &ctx->hist, &ctx->bin_starts, &ctx->own_sort_temp, &ctx->own_sort_keys, &ctx->own_sort_values,
                        &ctx->pair_geom, &ctx->pair_direct, &ctx->pair_range})
         b->release();
     for (rvb_ctx::CopyLane & l : ctx->copy_lanes) {
@@ -935,6 +938,7 @@ static int own_sort(rvb_ctx * ctx, const uint32_t * keys, uint32_t value_base, u
 
 static int ensure_sort_buffers(rvb_ctx * ctx, uint64_t n)
 {
+    if (n * 4 > ctx->keys_a.cap || n * 4 > ctx->vals_a.cap) ctx->flat_host = nullptr;      // the keys of a size query are about to be freed
     RVB_HIP(ctx, ctx->keys_a.ensure(n * 4));
     RVB_HIP(ctx, ctx->keys_b.ensure(n * 4));
     RVB_HIP(ctx, ctx->vals_a.ensure(n * 4));
@@ -993,12 +997,12 @@ int rvb_flatten(rvb_ctx * ctx, const rvb_attenuated_impulse * in, uint64_t n, fl
     uint64_t bins = ctx->flat_bins;
     if (!resident) {
         ctx->flat_host = nullptr;
-        RVB_HIP(ctx, ctx->scratch_in.ensure(n * sizeof(rvb_attenuated_impulse)));
+        RVB_HIP(ctx, ctx->flat_in.ensure(n * sizeof(rvb_attenuated_impulse)));
         if (n) {
-            int rc = rvb_copy_to_device(ctx, ctx->scratch_in.p, in, n * sizeof(rvb_attenuated_impulse));
+            int rc = rvb_copy_to_device(ctx, ctx->flat_in.p, in, n * sizeof(rvb_attenuated_impulse));
             if (rc != RVB_OK) return rc;
         }
-        int rc = flatten_keys(ctx, ctx->scratch_in.as<rvb_attenuated_impulse>(), n, sample_rate, &bins);
+        int rc = flatten_keys(ctx, ctx->flat_in.as<rvb_attenuated_impulse>(), n, sample_rate, &bins);
         if (rc != RVB_OK) return rc;
     }
     *nbins = bins;
@@ -1009,7 +1013,7 @@ int rvb_flatten(rvb_ctx * ctx, const rvb_attenuated_impulse * in, uint64_t n, fl
     ctx->flat_host = nullptr;                 // (the sort consumes the keys)
     if (capacity_bins < bins)
         return fail(ctx, RVB_ERR_CAPACITY, "rvb_flatten: capacity_bins too small");
-    return flatten_sum(ctx, ctx->scratch_in.as<rvb_attenuated_impulse>(), n, bins, out);
+    return flatten_sum(ctx, ctx->flat_in.as<rvb_attenuated_impulse>(), n, bins, out);
 }
 
 int rvb_flatten_device(rvb_ctx * ctx, const void * d_attenuated, uint64_t n, float sample_rate,
@@ -1310,6 +1314,7 @@ int rvb_ir_accumulate(rvb_ctx * ctx, float predelay, float sample_rate, uint64_t
     } else if (mode == RVB_IR_EXACT) {
         const uint64_t n = ndiffuse + nimages;
         if (n >= (1ull << 32)) return fail(ctx, RVB_ERR_CAPACITY, "rvb_ir_accumulate: too many impulses for exact mode");
+        ctx->flat_host = nullptr;                 // keys_a / vals_a are rewritten below: a pending rvb_flatten size query is void
         int rc = ensure_sort_buffers(ctx, n);
         if (rc != RVB_OK) return rc;
         if (nbins >= 0xFFFFFFFFull) return fail(ctx, RVB_ERR_CAPACITY, "rvb_ir_accumulate: too many bins for exact mode");

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <iostream>
 #include <list>
+#include <map>
 #include <mutex>
 #include <thread>
 
@@ -107,32 +108,38 @@ void parallel_ranges(size_t n, F f)
     for (std::thread & t : pool) t.join();
 }
 
-// ---- device copies of vectors this library handed out ------------------------------------------------------------------
-// The reference's API moves every stage's result through std::vector; its implementation re-uploads them stage by stage
-// (rayverb.cpp:863-875).  Here the producer of a vector remembers where its device copy lives, keyed by the vector's buffer
-// (address, element count), and the next stage uses that copy when it is handed the same buffer: Raytracer::getAllRaw ->
-// Attenuator::attenuate, attenuate -> fixPredelay -> flattenImpulses (the sequence of cmd/main.cpp:241-298).
-// A caller may have changed the vector in between.  Its length or address changing is caught by the key; an in-place edit is
-// caught by comparing a sample (every kSampleStride-th element, taken when the entry was made or last updated by this
-// library) — an edit confined to elements outside the sample is NOT seen; RVB_API_RESIDENT=0 turns the whole mechanism off.
+// ---- device copies of vectors this library handed out (OPT-IN: RVB_API_RESIDENT=1) ---------------------------------------
+// The reference's API moves every stage's result through std::vector and its implementation uploads whatever vector it is handed,
+// stage by stage (rayverb.cpp:863-875).  That is what this mirror does by default: every stage uploads the vector it receives.
+//
+// With RVB_API_RESIDENT=1 in the environment the CALLER PROMISES not to edit a vector this library returned between the
+// stages of the sequence Raytracer::getAllRaw -> Attenuator::attenuate -> fixPredelay -> flattenImpulses (cmd/main.cpp:241-298
+// does not).  The producer of a vector then remembers where its device copy lives, keyed by the vector's buffer (address,
+// element count), and the next stage uses that copy instead of uploading.  A changed length or address is caught by the key and a
+// sample of the contents (every kSampleStride-th element) is compared as a courtesy, but an in-place edit that misses the sample
+// is NOT seen — checking all of a 0.8 GB vector costs as much host-memory traffic as uploading it, which is why the mechanism
+// is a promise the caller opts into and not the default.
 const size_t kSampleStride = 251;
+const size_t kResidentByteCap = (size_t) 6 << 30;      // owned device copies kept at a time (bytes), oldest dropped first
 
 struct Resident {
     const void * host = nullptr;      // the vector's buffer
     size_t count = 0, elem = 0;       // elements, bytes per element
     void * device = nullptr;          // device copy (of `device_count` leading elements)
     size_t device_count = 0;
-    bool owned = false;               // allocated for this entry (freed with it) / borrowed from a Raytracer's context
-    const void * owner = nullptr;     // the Raytracer whose trace buffer is borrowed
+    bool owned = false;               // allocated for this entry (freed with it) / borrowed from a tracing context
+    const rvb_ctx * owner = nullptr;  // borrowed: the context whose trace buffer this is (copies of a Raytracer share it) ...
+    uint64_t generation = 0;          // ... and that context's trace count when the entry was made: a later trace voids the entry
     std::vector<unsigned char> sample;
 };
 
 std::mutex g_resident_mutex;
 std::list<Resident> g_resident;
+std::map<const rvb_ctx *, uint64_t> g_trace_generation;       // traces started per context (guarded by g_resident_mutex)
 
 bool resident_enabled()
 {
-    static const bool on = !(std::getenv("RVB_API_RESIDENT") && std::getenv("RVB_API_RESIDENT")[0] == '0');
+    static const bool on = std::getenv("RVB_API_RESIDENT") && std::getenv("RVB_API_RESIDENT")[0] == '1';
     return on;
 }
 
@@ -152,22 +159,51 @@ void release_entry(Resident & r)
     r.device = nullptr;
 }
 
-void resident_forget_owner(const void * owner)
+// a context is about to trace (or goes away): its trace buffer no longer holds what the borrowed entries describe
+void resident_new_trace(const rvb_ctx * owner)
 {
     std::lock_guard<std::mutex> lock(g_resident_mutex);
+    ++g_trace_generation[owner];
     for (auto it = g_resident.begin(); it != g_resident.end();)
-        if (it->owner == owner) { release_entry(*it); it = g_resident.erase(it); } else ++it;
+        if (!it->owned && it->owner == owner) it = g_resident.erase(it); else ++it;
+}
+
+uint64_t resident_generation(const rvb_ctx * owner)
+{
+    std::lock_guard<std::mutex> lock(g_resident_mutex);
+    return g_trace_generation[owner];
+}
+
+// drops owned device copies, oldest first, until at most `keep_bytes` of them remain; returns whether anything was freed
+bool resident_evict(size_t keep_bytes)
+{
+    std::lock_guard<std::mutex> lock(g_resident_mutex);
+    size_t held = 0;
+    for (const Resident & r : g_resident) if (r.owned) held += r.device_count * r.elem;
+    bool freed = false;
+    while (held > keep_bytes && !g_resident.empty()) {
+        auto it = g_resident.end();
+        for (auto j = g_resident.begin(); j != g_resident.end(); ++j) if (j->owned) it = j;      // the last owned entry = the oldest
+        if (it == g_resident.end()) break;
+        held -= it->device_count * it->elem;
+        release_entry(*it);
+        g_resident.erase(it);
+        freed = true;
+    }
+    return freed;
 }
 
 void resident_remember(Resident r)
 {
     if (!resident_enabled()) { release_entry(r); return; }
     r.sample = take_sample(r.host, r.count, r.elem);
-    std::lock_guard<std::mutex> lock(g_resident_mutex);
-    for (auto it = g_resident.begin(); it != g_resident.end();)      // a buffer address names one vector at a time
-        if (it->host == r.host) { release_entry(*it); it = g_resident.erase(it); } else ++it;
-    g_resident.push_front(std::move(r));
-    while (g_resident.size() > 24) { release_entry(g_resident.back()); g_resident.pop_back(); }
+    {
+        std::lock_guard<std::mutex> lock(g_resident_mutex);
+        for (auto it = g_resident.begin(); it != g_resident.end();)      // a buffer address names one vector at a time
+            if (it->host == r.host) { release_entry(*it); it = g_resident.erase(it); } else ++it;
+        g_resident.push_front(std::move(r));
+    }
+    (void) resident_evict(kResidentByteCap);
 }
 
 // the entry of (host, count) if the vector still reads as it did; stale entries are dropped
@@ -177,7 +213,8 @@ bool resident_find(const void * host, size_t count, size_t elem, Resident & out)
     std::lock_guard<std::mutex> lock(g_resident_mutex);
     for (auto it = g_resident.begin(); it != g_resident.end(); ++it) {
         if (it->host != host) continue;
-        if (it->count == count && it->elem == elem && it->sample == take_sample(host, count, elem)) { out = *it; out.sample.clear(); return true; }
+        const bool current = it->owned || g_trace_generation[it->owner] == it->generation;
+        if (current && it->count == count && it->elem == elem && it->sample == take_sample(host, count, elem)) { out = *it; out.sample.clear(); return true; }
         release_entry(*it);
         g_resident.erase(it);
         return false;
@@ -190,6 +227,15 @@ void resident_resample(const void * host, size_t count, size_t elem)
     std::lock_guard<std::mutex> lock(g_resident_mutex);
     for (Resident & r : g_resident)
         if (r.host == host && r.count == count && r.elem == elem) r.sample = take_sample(host, count, elem);
+}
+
+// rvb_device_alloc that gives the resident cache's device copies back before it reports a failure
+int device_alloc_evicting(rvb_ctx * ctx, uint64_t bytes, void ** d_ptr)
+{
+    int rc = rvb_device_alloc(ctx, bytes, d_ptr);
+    if (rc != RVB_OK && resident_evict(0))
+        rc = rvb_device_alloc(ctx, bytes, d_ptr);
+    return rc;
 }
 
 void throw_on(int rc, rvb_ctx * ctx, const char * where)
@@ -397,13 +443,15 @@ void Raytracer::upload(std::vector<Triangle> & triangles, std::vector<cl_float3>
 
 Raytracer::~Raytracer()
 {
-    resident_forget_owner(this);               // entries that borrow this tracer's trace buffer
+    // entries that borrow the context's trace buffer: void once the context may go away (copies of this object share the
+    // context; treating every destruction as the end of the buffer only costs an upload)
+    resident_new_trace(context());
 }
 
 void Raytracer::raytrace(const cl_float3 & micpos, const cl_float3 & source, const std::vector<cl_float3> & directions, bool verbose)
 {
     storedMicpos = micpos;
-    resident_forget_owner(this);               // the trace buffer is about to be overwritten
+    resident_new_trace(context());             // the trace buffer is about to be overwritten (copies of this object share it)
 
     // reference rayverb.cpp:547-583: warn when mic or source lie outside the model's bounding box
     const bool micinside = inside(bounds, micpos);
@@ -453,7 +501,8 @@ void Raytracer::fetchDiffuse(std::vector<Impulse> & out)
     if (n && rvb_diffuse_device(context(), &d, &count) == RVB_OK && count == n) {
         Resident r;
         r.host = out.data(); r.count = out.size(); r.elem = sizeof(Impulse);
-        r.device = const_cast<void *>(d); r.device_count = n; r.owned = false; r.owner = this;
+        r.device = const_cast<void *>(d); r.device_count = n; r.owned = false; r.owner = context();
+        r.generation = resident_generation(context());
         resident_remember(r);
     }
 }
@@ -583,13 +632,13 @@ void stage_impulses(const std::vector<Impulse> & impulses, DeviceImpulses & dev)
         dev.nhead = r.device_count;
         dev.ntail = n - r.device_count;
         if (dev.ntail) {
-            throw_on(rvb_device_alloc(ctx, dev.ntail * sizeof(Impulse), &dev.tail), ctx, "rvb_device_alloc");
+            throw_on(device_alloc_evicting(ctx, dev.ntail * sizeof(Impulse), &dev.tail), ctx, "rvb_device_alloc");
             throw_on(rvb_copy_to_device(ctx, dev.tail, impulses.data() + dev.nhead, dev.ntail * sizeof(Impulse)), ctx, "rvb_copy_to_device");
         }
         return;
     }
     if (n == 0) return;
-    throw_on(rvb_device_alloc(ctx, n * sizeof(Impulse), &dev.upload), ctx, "rvb_device_alloc");
+    throw_on(device_alloc_evicting(ctx, n * sizeof(Impulse), &dev.upload), ctx, "rvb_device_alloc");
     throw_on(rvb_copy_to_device(ctx, dev.upload, impulses.data(), n * sizeof(Impulse)), ctx, "rvb_copy_to_device");
     dev.head = dev.upload;
     dev.nhead = n;
@@ -602,7 +651,7 @@ std::vector<AttenuatedImpulse> attenuate_channel(rvb_ctx * ctx, size_t n, Launch
     std::vector<AttenuatedImpulse> ret = uninitialized_vector<AttenuatedImpulse>(n);
     if (n == 0) return ret;
     void * d_out = nullptr;
-    throw_on(rvb_device_alloc(ctx, n * sizeof(AttenuatedImpulse), &d_out), ctx, "rvb_device_alloc");
+    throw_on(device_alloc_evicting(ctx, n * sizeof(AttenuatedImpulse), &d_out), ctx, "rvb_device_alloc");
     int rc = launch(d_out);
     if (rc == RVB_OK) rc = rvb_copy_to_host(ctx, ret.data(), d_out, n * sizeof(AttenuatedImpulse));
     if (rc != RVB_OK) { (void) rvb_device_free(ctx, d_out); throw_on(rc, ctx, "attenuate"); }

@@ -11,6 +11,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <iostream>
 #include <random>
@@ -250,6 +251,49 @@ int main()
                 { ++failures; std::printf("FAIL edited results\n"); }
             auto edited_att = resident;
             if (flattenImpulses(resident, 44100.0f) != flattenImpulses(edited_att, 44100.0f)) { ++failures; std::printf("FAIL edited attenuated\n"); }
+            // The default mode uploads whatever vector a stage is handed (reference rayverb.cpp:863-875): an edit of ANY element
+            // between two stages is seen.  Elements 1 and 7 are outside every sample RVB_API_RESIDENT=1 would compare (stride 251),
+            // which is exactly the case that mode's contract excludes ("the caller does not edit the vectors").
+            const bool promised = std::getenv("RVB_API_RESIDENT") && std::getenv("RVB_API_RESIDENT")[0] == '1';
+            if (!promised) {
+                tracer.raytrace(mic, src, dirs, false);
+                RaytracerResults fresh = tracer.getAllRaw(false);
+                const auto before = SpeakerAttenuator().attenuate(fresh, speakers);
+                fresh.impulses[1].volume.s[2] = 55.0f;                             // ONE impulse, not element 0, 251, ...
+                fresh.impulses[1].time = 0.125f;
+                auto after = SpeakerAttenuator().attenuate(fresh, speakers);
+                RaytracerResults fresh_copy(fresh.impulses, fresh.mic);
+                if (!same(after, SpeakerAttenuator().attenuate(fresh_copy, speakers))) { ++failures; std::printf("FAIL one edited impulse: stale input used\n"); }
+                if (same(after, before)) { ++failures; std::printf("FAIL one edited impulse: edit not seen\n"); }
+                after[0][7].volume.s[5] = 3.5f;                                    // ... and one attenuated impulse before the binning
+                after[0][7].time = 0.01f;
+                auto after_copy = after;
+                const auto flat_edit = flattenImpulses(after, 44100.0f);
+                if (flat_edit != flattenImpulses(after_copy, 44100.0f)) { ++failures; std::printf("FAIL one edited attenuated impulse: stale input used\n"); }
+                fixPredelay(after);
+                fixPredelay(after_copy);
+                after[1][7].volume.s[0] = -2.0f;
+                after_copy[1][7].volume.s[0] = -2.0f;
+                if (flattenImpulses(after, 44100.0f) != flattenImpulses(after_copy, 44100.0f)) { ++failures; std::printf("FAIL edit after fixPredelay: stale input used\n"); }
+                // a copy of the tracer shares its context: a trace through the copy must not leave the original's results readable as current
+                Raytracer twin(tracer);
+                RaytracerResults mine = tracer.getRawDiffuse();
+                const cl_float3 elsewhere = {{1, 2, 1}};
+                twin.raytrace(elsewhere, src, dirs, false);
+                RaytracerResults mine_copy(mine.impulses, mine.mic);
+                if (!same(SpeakerAttenuator().attenuate(mine, speakers), SpeakerAttenuator().attenuate(mine_copy, speakers)))
+                    { ++failures; std::printf("FAIL results of a tracer whose copy traced again\n"); }
+            } else {
+                // opt-in mode: the same copied-tracer sequence must not serve the twin's trace buffer for the original's vector
+                tracer.raytrace(mic, src, dirs, false);
+                Raytracer twin(tracer);
+                RaytracerResults mine = tracer.getRawDiffuse();
+                const cl_float3 elsewhere = {{1, 2, 1}};
+                twin.raytrace(elsewhere, src, dirs, false);
+                RaytracerResults mine_copy(mine.impulses, mine.mic);
+                if (!same(SpeakerAttenuator().attenuate(mine, speakers), SpeakerAttenuator().attenuate(mine_copy, speakers)))
+                    { ++failures; std::printf("FAIL (resident) results of a tracer whose copy traced again\n"); }
+            }
             // HRTF attenuator through the same handover
             tracer.raytrace(mic, src, dirs, false);
             RaytracerResults again = tracer.getRawDiffuse();

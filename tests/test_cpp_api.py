@@ -34,8 +34,12 @@ def test_cpp_api_compiles_and_refuses_to_run_without_gpu():
 
 
 @pytest.mark.gpu
-def test_reference_gtest_suites_through_cpp_api():
+@pytest.mark.parametrize("resident", ["0", "1"])
+def test_reference_gtest_suites_through_cpp_api(resident):
+    """Default mode (every stage uploads the vector it is handed, as the reference does: an edit of any single element
+    between stages is seen) and the opt-in device-resident handover (RVB_API_RESIDENT=1)."""
     _build()
-    r = subprocess.run([BIN], capture_output=True, text=True, cwd=ROOT, timeout=300)
+    env = dict(os.environ, RVB_API_RESIDENT=resident)
+    r = subprocess.run([BIN], capture_output=True, text=True, cwd=ROOT, timeout=300, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "all reference gtest cases passed" in r.stdout

@@ -195,8 +195,27 @@ def check_every_ray_against_gpu_brute_force(ctx, oracle, gpu_oracle, scene, mic,
         assert ctx.get_image_candidates().tobytes() == cands.tobytes()
     finally:
         ctx.set_concurrent_traces(1)
+    # ... and the kernel the bench pipeline times: the traces of TWO contexts in ONE launch (rvb_trace_group ->
+    # path_pair_group_kernel), same scene, rays, source and microphone on both, as distributed.IrPipeline issues them
+    group_checked = False
+    if 2 * nrays >= 196608:
+        from parallel_reverb_raytracer_amd import capi
+        other = capi.Context(0)
+        try:
+            other.set_scene(scene)
+            for c in (ctx, other):
+                c.set_directions(dirs)
+            capi.Context.trace_group([ctx, other], [mic, mic], [src, src], nrefl, AIR_COEFFICIENTS, [0, 0])
+            want_crc, want_cands = _crc(got), cands.tobytes()
+            for c in (ctx, other):
+                assert "path_pair_kernel" in dict(c.last_timings()), "the group launch did not use the two-lane group kernel"
+                assert _crc(c.get_raw_diffuse()) == want_crc, "a trace of the two-trace group launch differs from the same trace alone"
+                assert c.get_image_candidates().tobytes() == want_cands
+            group_checked = True
+        finally:
+            other.close()
     return {"rays": int(nrays), "impulses": int(got.shape[0]), "volume_values_off_by_one_ulp": int((ulps == 1).sum()),
-            "image_source_slots": int(rays.shape[0]), "both_path_kernels": True}
+            "image_source_slots": int(rays.shape[0]), "both_path_kernels": True, "two_trace_group_launch": group_checked}
 
 
 def test_c2_every_ray_of_the_full_run_against_brute_force_on_the_gpu(ctx, oracle, gpu_oracle):

@@ -413,6 +413,56 @@ def test_flatten_is_bit_exact_with_serial_order(ctx, oracle):
         assert got.shape == want.shape and np.array_equal(got, want), n
 
 
+def test_flatten_fill_after_other_calls_on_the_context_is_not_served_from_overwritten_buffers(ctx, oracle):
+    """rvb_flatten's size query leaves the uploaded array and its keys on the device for the fill that follows.  Anything
+    else the context does in between — a materialised attenuate (its own staging buffers), an exact-mode IR (the sort
+    buffers), another flatten — must not turn that fill into a histogram of overwritten data."""
+    import ctypes
+    from parallel_reverb_raytracer_amd import capi
+    rng = np.random.default_rng(81)
+    n = 30000
+    att = dtypes.aligned_zeros(n, dtypes.ATTENUATED)
+    att["volume"] = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
+    att["time"] = rng.uniform(0, 0.05, n).astype(np.float32)
+    want = oracle.flatten(att, 44100.0)
+    lib, h = ctx.lib, ctx.handle
+
+    def query():
+        nb = ctypes.c_uint64(0)
+        ctx._check(lib.rvb_flatten(h, att.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(n), ctypes.c_float(44100.0), None, ctypes.c_uint64(0), ctypes.byref(nb)))
+        return nb.value
+
+    def fill(nb):
+        out = np.zeros((8, nb), np.float32)
+        got = ctypes.c_uint64(0)
+        ctx._check(lib.rvb_flatten(h, att.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(n), ctypes.c_float(44100.0),
+                                   out.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(nb), ctypes.byref(got)))
+        return out
+
+    imp = dtypes.aligned_zeros(n, dtypes.IMPULSE)
+    imp["volume"] = rng.uniform(-1, 1, (n, 8)).astype(np.float32)
+    imp["position"][:, :3] = rng.uniform(-5, 5, (n, 3)).astype(np.float32)
+    imp["time"] = rng.uniform(0, 1, n).astype(np.float32)
+    # 1. query -> materialised attenuate on the same context -> fill
+    nb = query()
+    ctx.attenuate_speaker((0, 1, 0), imp, (0.3, -1, 0.2), 0.7)
+    assert np.array_equal(fill(nb), want)
+    # 2. query -> exact-mode IR on the same context (rewrites the sort buffers) -> fill
+    scene, info = scenes.cathedral(3000)
+    ctx.set_scene(scene)
+    ctx.raytrace(info["mic"], info["source"], scenes.sphere_directions(2048, seed=3), 32, AIR_COEFFICIENTS)
+    nb = query()
+    ctx.ir_configure_speakers(info["mic"], [(-1, 0, -1), (1, 0, -1)], [0.5, 0.5], capi.IR_ALL, ctx.get_raw_images(False))
+    ctx.ir_download(True, 44100.0, capi.IR_EXACT)
+    assert np.array_equal(fill(nb), want)
+    # 3. query -> flatten of another array -> fill
+    other = att.copy()
+    other["time"] *= np.float32(0.5)
+    nb = query()
+    assert np.array_equal(ctx.flatten(other, 44100.0), oracle.flatten(other, 44100.0))
+    assert np.array_equal(fill(nb), want)
+
+
 def _oracle_ir(oracle, mic, impulses, speakers, trim, sr, hrtf=None):
     if hrtf is None:
         chans = [oracle.attenuate_speaker(mic, impulses, d, c) for d, c in speakers]

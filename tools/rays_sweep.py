@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Developer tool: duration of the path kernel alone on the GPU as a function of the number of rays in the launch, at the C2
+scene — shows where a launch stops fitting in one resident round of waves (the waves beyond it start when the first ones finish
+and then run a whole 128-bounce chain almost alone).  RVB_PATH_LANES=2|4 picks the kernel (read once per process).
+    RVB_PATH_LANES=2 python tools/rays_sweep.py 163840 196608 200000 ...
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import rvb_import  # noqa: E402
+
+rvb_import.load()
+from parallel_reverb_raytracer_amd import capi, dtypes, scenes  # noqa: E402
+
+
+def main():
+    counts = [int(x) for x in sys.argv[1:]] or [100000, 200000]
+    nrefl = int(os.environ.get("SWEEP_REFLECTIONS", "128"))
+    (scene, info) = scenes.cathedral(int(os.environ.get("SWEEP_TRIANGLES", "75000")))
+    ctx = capi.Context(0)
+    ctx.set_scene(scene)
+    for n in counts:
+        ctx.set_directions(scenes.sphere_directions(n, seed=1))
+        times = {}
+        for _ in range(4):
+            ctx.trace(info["mic"], info["source"], nrefl, dtypes.AIR_COEFFICIENTS)
+            ctx.synchronize()
+            for k, v in ctx.last_timings():
+                times.setdefault(k, []).append(v)
+        line = " ".join("%s %.3f" % (k, float(np.median(v[1:]))) for k, v in times.items())
+        path = [float(np.median(v[1:])) for k, v in times.items() if k.startswith("path")][0]
+        print("lanes %s rays %d path/100k %.3f | %s" % (os.environ.get("RVB_PATH_LANES", "auto"), n, path * 1e5 / n, line), flush=True)
+
+
+if __name__ == "__main__":
+    main()
