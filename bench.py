@@ -227,31 +227,33 @@ def main():
                 for k, v in tracer.last_timings():
                     sink.setdefault(k, []).append(v)
         return dict(speakers_dir=speakers_dir, speakers_coeff=speakers_coeff, sample_rate=sr, trim_predelay=True,
-                    mode=mode if ir_mode is None else ir_mode,
+                    mode=mode if ir_mode is None else ir_mode, host_out=host_out if to_host else None,
                     rank=rank, world=world, ray_offset=first_ray, device=device, on_stage=on_stage, collectives=grouped)
 
-    # an impulse response is generated once [channels][8][nbins] is ON THE HOST.  Every finished histogram is
-    # copied to pinned host memory on a side stream (54 MB at C2, about 1 ms of PCIe beside the next IRs' kernels); the timed
-    # region ends when the last copy has landed (fence() waits for every stream of the device).
+    # an impulse response is generated once [channels][8][nbins] is ON THE HOST.  Every histogram is copied to
+    # pinned host memory behind its binning (rvb_copy_to_pinned_host_async: 54 MB at C2, about a millisecond of PCIe, on the
+    # context's export stream beside the next IRs' kernels); the timed region ends when the last copy has landed (fence() waits for
+    # every stream of the device).
     to_host = not args.no_host_copy
-    copy_stream = torch.cuda.Stream(device) if to_host else None
-    host_ring = []
+    host_ring, in_flight = [], {}
 
-    def keep(hist, info, _tracer):
-        state.update(hist=hist, nbins=info["nbins"], images=info["images"], predelay=info["predelay"])
-        if not to_host:
-            return
-        if not host_ring or host_ring[0].shape != hist.shape:
-            host_ring[:] = [torch.empty(hist.shape, dtype=hist.dtype, pin_memory=True) for _ in range(4)]
+    def host_out(shape):
+        if not host_ring or tuple(host_ring[0].shape) != tuple(shape):
+            torch.cuda.synchronize()
+            host_ring[:] = [torch.empty(shape, dtype=torch.float32, pin_memory=True) for _ in range(2 * max(1, args.contexts))]
+            in_flight.clear()
             state["slot"] = 0
-        buf = host_ring[state["slot"] % len(host_ring)]
+        slot = state["slot"] % len(host_ring)
         state["slot"] += 1
-        # (the binning ran on the context's stream and the host has waited for it; the all-reduce, if any, is ordered on torch's current stream)
-        copy_stream.wait_stream(torch.cuda.current_stream(device))
-        with torch.cuda.stream(copy_stream):
-            buf.copy_(hist, non_blocking=True)
-        hist.record_stream(copy_stream)                    # the allocator must not hand the block out again before the copy has read it
-        state["host"] = buf
+        if slot in in_flight:                               # the copy that last used this buffer (2 x contexts IRs ago): done long since
+            in_flight.pop(slot)[1].synchronize_exports()
+        state["last_slot"] = slot
+        return host_ring[slot]
+
+    def keep(hist, info, tracer):
+        state.update(hist=hist, nbins=info["nbins"], images=info["images"], predelay=info["predelay"], host=info.get("host"))
+        if info.get("host") is not None:
+            in_flight[state["last_slot"]] = (hist, tracer)  # the device histogram stays alive until its copy has left
 
     def fence():
         for c in contexts:
@@ -283,18 +285,20 @@ def main():
     solo_irs = 4
     t0 = time.perf_counter()
     for _ in range(solo_irs):
-        distributed.generate_ir(ctx, *trace_args, **ir_kwargs(solo_ms))
+        h, _ = distributed.generate_ir(ctx, *trace_args, **ir_kwargs(solo_ms))
         ctx.synchronize()
+        ctx.synchronize_exports()
     solo_latency_ms = (time.perf_counter() - t0) * 1e3 / solo_irs
-    hist, _ = distributed.generate_ir(ctx, *trace_args, **ir_kwargs(None))
-    host_hist = torch.empty(hist.shape, dtype=hist.dtype, pin_memory=True)
+    in_hbm = dict(ir_kwargs(None), host_out=None)
+    for _ in range(solo_irs):
+        distributed.generate_ir(ctx, *trace_args, **in_hbm)
     fence()
     t0 = time.perf_counter()
     for _ in range(solo_irs):
-        hist, _ = distributed.generate_ir(ctx, *trace_args, **ir_kwargs(None))
-        host_hist.copy_(hist, non_blocking=True)
-        torch.cuda.synchronize()
-    to_host_latency_ms = (time.perf_counter() - t0) * 1e3 / solo_irs
+        distributed.generate_ir(ctx, *trace_args, **in_hbm)
+        ctx.synchronize()
+    hbm_latency_ms = (time.perf_counter() - t0) * 1e3 / solo_irs
+    to_host_latency_ms, solo_latency_ms = solo_latency_ms, hbm_latency_ms      # (the first solo pass above ran with the host copy)
     for c in contexts:
         c.set_concurrent_traces(pipeline.group_size(len(contexts)))
     if pipeline.group_size(len(contexts)) > 1:
@@ -315,12 +319,14 @@ def main():
     value = bounces_per_step / (elapsed / args.steps)
     executed = ctx.executed_bounces()
 
+    if rank == 0:
+        print("bench.py: timed region %.3f ms per step" % ms_per_step, file=sys.stderr)
     # What the timed region produced must be what one IR generated strictly alone produces: the last histogram of the pipelined,
     # fused (two traces per path-kernel launch) region — as it landed on the host — against a solo IR of the same arguments.
     # Exact mode on one rank: bit for bit (the serial-order sum has one value).  Several ranks add their serial sums with an
     # all-reduce, float atomics have no fixed order: there the bar is the stated tolerance, 1e-5 of each band's largest value.
     timed_hist = (state["host"] if to_host else state["hist"].cpu()).clone()
-    solo_hist, _ = distributed.generate_ir(ctx, *trace_args, **ir_kwargs(None))
+    solo_hist, _ = distributed.generate_ir(ctx, *trace_args, **dict(ir_kwargs(None), host_out=None))
     fence()
     solo_host = solo_hist.cpu()
     bit_equal = bool(torch.equal(timed_hist, solo_host))

@@ -206,6 +206,17 @@ int rvb_device_free(rvb_ctx * ctx, void * d_ptr);
  * pageable memory runs at a fraction of the link rate).  Synchronous; ordered after the work already on the context's stream. */
 int rvb_copy_to_host(rvb_ctx * ctx, void * dst, const void * d_src, uint64_t bytes);
 int rvb_copy_to_device(rvb_ctx * ctx, void * d_dst, const void * src, uint64_t bytes);
+/* Pinned (page-locked, device-mapped) host memory, and a device -> pinned-host copy that is ASYNCHRONOUS: it starts when the work
+ * enqueued so far on the context's stream has finished (e.g. the rvb_ir_accumulate that fills d_src) and runs on a stream of its
+ * own, so the context's next trace does not wait for the link; rvb_synchronize_exports waits for it (rvb_synchronize does not).
+ * d_src must stay untouched until then.  This is what carries a finished [nchannels][8][nbins] histogram to the host.
+ * pinned_dst should be pinned memory (rvb_host_alloc, hipHostMalloc, torch's pin_memory): into pageable memory the runtime's
+ * copy is staged and blocks the caller.  The reference's counterpart is the blocking cl::copy of every result buffer
+ * (rayverb.cpp:645-651, :678, :816). */
+int rvb_host_alloc(rvb_ctx * ctx, uint64_t bytes, void ** host_ptr);
+int rvb_host_free(rvb_ctx * ctx, void * host_ptr);
+int rvb_copy_to_pinned_host_async(rvb_ctx * ctx, void * pinned_dst, const void * d_src, uint64_t bytes);
+int rvb_synchronize_exports(rvb_ctx * ctx);
 /* fixPredelay (rayverb.h:76-90) on a device-resident AttenuatedImpulse array: time = time > seconds ? time - seconds : 0. */
 int rvb_fix_predelay_device(rvb_ctx * ctx, void * d_attenuated, uint64_t n, float seconds);
 /* rvb_flatten on a device-resident AttenuatedImpulse array (same result, no upload). */

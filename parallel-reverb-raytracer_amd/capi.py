@@ -31,6 +31,7 @@ SYMBOLS = [
     "rvb_ir_configure_speakers", "rvb_ir_configure_hrtf", "rvb_ir_time_range", "rvb_ir_bins", "rvb_ir_accumulate",
     "rvb_ir_download", "rvb_last_timings", "rvb_debug_stamps", "rvb_executed_bounces",
     "rvb_device_alloc", "rvb_device_free", "rvb_copy_to_host", "rvb_copy_to_device", "rvb_fix_predelay_device", "rvb_flatten_device",
+    "rvb_host_alloc", "rvb_host_free", "rvb_copy_to_pinned_host_async", "rvb_synchronize_exports",
     "rvb_multi_create", "rvb_multi_destroy", "rvb_multi_last_error", "rvb_multi_devices", "rvb_multi_context", "rvb_multi_used_rccl",
     "rvb_multi_set_scene", "rvb_multi_set_directions", "rvb_multi_trace", "rvb_multi_get_diffuse", "rvb_multi_get_images",
     "rvb_multi_ir_speakers", "rvb_multi_ir_hrtf",
@@ -337,6 +338,14 @@ class Context:
         self._check(self.lib.rvb_ir_accumulate(self.handle, ctypes.c_float(predelay), ctypes.c_float(sample_rate), _u64(nbins),
                                                ctypes.c_int(mode), _vp(device_histogram_pointer)))
 
+    def ir_accumulate_wait_for_torch(self):
+        """The context's stream waits (by an event, not the host) for everything enqueued so far on torch's current stream."""
+        import torch
+        ready = torch.cuda.Event()
+        ready.record()
+        self._check(self.lib.rvb_wait_for_event(self.handle, _vp(ready.cuda_event)))
+        self._keep_event2 = ready
+
     def ir_accumulate_tensor(self, predelay, sample_rate, nbins, mode, tensor):
         """Adds into a zeroed torch CUDA tensor [nchannels][8][nbins] (plumbing for distributed.py).  The tensor was
         filled on torch's current stream: the context's stream waits for that fill through an event, the host does not."""
@@ -347,6 +356,18 @@ class Context:
         self._check(self.lib.rvb_wait_for_event(self.handle, _vp(ready.cuda_event)))
         self.ir_accumulate(predelay, sample_rate, nbins, mode, tensor.data_ptr())
         self._keep_event = ready                       # alive until the next call (the wait has been enqueued, not executed)
+
+    def export_tensor_to_host(self, tensor, pinned_host_tensor):
+        """Enqueues, behind the binning, the copy of a device tensor (the histogram ir_accumulate_tensor filled) into a PINNED host
+        tensor of the same size (rvb_copy_to_pinned_host_async: on the context's export stream); synchronize_exports()
+        waits for it, synchronize() does not.  The caller keeps `tensor` alive and untouched until then."""
+        assert tensor.is_cuda and tensor.is_contiguous() and pinned_host_tensor.is_pinned() and pinned_host_tensor.is_contiguous()
+        assert tensor.numel() * tensor.element_size() == pinned_host_tensor.numel() * pinned_host_tensor.element_size()
+        self._check(self.lib.rvb_copy_to_pinned_host_async(self.handle, _vp(pinned_host_tensor.data_ptr()), _vp(tensor.data_ptr()),
+                                                           _u64(tensor.numel() * tensor.element_size())))
+
+    def synchronize_exports(self):
+        self._check(self.lib.rvb_synchronize_exports(self.handle))
 
     def ir_download(self, trim_predelay, sample_rate, mode=IR_FAST):
         """attenuate -> fixPredelay -> flattenImpulses (reference cmd/main.cpp:280-298) -> [nch][8][nbins]."""

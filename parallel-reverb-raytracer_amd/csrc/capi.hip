@@ -42,6 +42,8 @@ struct rvb_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t side_stream = nullptr;          // image_kernel runs here, beside the record grouping
+    hipStream_t export_stream = nullptr;        // rvb_copy_to_pinned_host_async: results leave for the host beside the next trace
+    hipEvent_t export_ready = nullptr;
     hipEvent_t path_done = nullptr, side_done = nullptr;
     hipEvent_t prep_done = nullptr, group_done = nullptr;      // rvb_trace_group: this context's fills are enqueued / the group's path kernel is
     std::string error;
@@ -76,8 +78,12 @@ struct rvb_ctx {
     std::vector<rvb_impulse> pair_direct_host;
     std::vector<uint32_t> pair_range_host;
     DevBuf impulses, early, candidates, small, stamps, sort_keys, sort_scratch, sort_order, group_temp;       // small: [0] candidate count, [2..3] executed, [16..] direct, range
-    unsigned char small_host[128] = {0};        // host mirror of `small`, fetched once per trace
-    rvb_image_candidate first_candidates[32];   // ... together with the first few image-source candidates (usually all of them)
+    // host mirror of `small`, fetched once per trace together with the first few image-source candidates (usually all of them).
+    // One PINNED block: a device-to-host copy into pageable memory is staged by the runtime and blocks the host per call (three
+    // round trips of 30-160 us between the shadow kernel and the binning stage in a kernel trace); into pinned memory the copies
+    // are asynchronous and the host waits once.
+    unsigned char * small_host = nullptr;       // [kSmallBytes]
+    rvb_image_candidate * first_candidates = nullptr;   // [kFirstCandidates], behind small_host in the same block
     bool small_valid = false;
     std::vector<Timing> timings;
     std::vector<hipEvent_t> event_pool;
@@ -164,6 +170,7 @@ const size_t kSmallMaxTime = 24;    // uint32
 const size_t kSmallTraceRange = 32; // two uint32: time range of the traced diffuse impulses (shadow_kernel)
 const size_t kSmallDirect = 64;     // rvb_impulse
 const size_t kSmallBytes = 128;
+const size_t kFirstCandidates = 32;
 
 uint64_t bins_for(float max_time, float predelay, float sample_rate)
 {
@@ -213,15 +220,20 @@ int rvb_create(rvb_ctx ** out, int device, unsigned flags)
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest)) != hipSuccess ||
         (e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_greatest)) != hipSuccess ||
         (e = hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, prio_least)) != hipSuccess ||
+        (e = hipStreamCreateWithPriority(&ctx->export_stream, hipStreamNonBlocking, (prio_least + prio_greatest) / 2)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->export_ready, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->path_done, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->side_done, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->prep_done, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->group_done, hipEventDisableTiming)) != hipSuccess ||
-        (e = ctx->small.ensure(kSmallBytes)) != hipSuccess) {
+        (e = ctx->small.ensure(kSmallBytes)) != hipSuccess ||
+        (e = hipHostMalloc(reinterpret_cast<void **>(&ctx->small_host), kSmallBytes + kFirstCandidates * sizeof(rvb_image_candidate), hipHostMallocDefault)) != hipSuccess) {
         std::string what = std::string("rvb_create: ") + hipGetErrorString(e);
         delete ctx;
         return fail(nullptr, RVB_ERR_HIP, what);
     }
+    std::memset(ctx->small_host, 0, kSmallBytes + kFirstCandidates * sizeof(rvb_image_candidate));
+    ctx->first_candidates = reinterpret_cast<rvb_image_candidate *>(ctx->small_host + kSmallBytes);
     *out = ctx;
     return RVB_OK;
 }
@@ -241,6 +253,7 @@ void rvb_destroy(rvb_ctx * ctx)
         for (int i = 0; i < 2; ++i) { if (l.pinned[i]) (void) hipHostFree(l.pinned[i]); if (l.done[i]) (void) hipEventDestroy(l.done[i]); }
         if (l.stream) (void) hipStreamDestroy(l.stream);
     }
+    if (ctx->small_host) (void) hipHostFree(ctx->small_host);
     if (ctx->pair_stage) (void) hipHostFree(ctx->pair_stage);
     if (ctx->pair_stage_free) (void) hipEventDestroy(ctx->pair_stage_free);
     for (hipEvent_t e : ctx->event_pool) (void) hipEventDestroy(e);
@@ -249,6 +262,8 @@ void rvb_destroy(rvb_ctx * ctx)
     if (ctx->prep_done) (void) hipEventDestroy(ctx->prep_done);
     if (ctx->group_done) (void) hipEventDestroy(ctx->group_done);
     if (ctx->side_stream) { (void) hipStreamSynchronize(ctx->side_stream); (void) hipStreamDestroy(ctx->side_stream); }
+    if (ctx->export_stream) { (void) hipStreamSynchronize(ctx->export_stream); (void) hipStreamDestroy(ctx->export_stream); }
+    if (ctx->export_ready) (void) hipEventDestroy(ctx->export_ready);
     if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -667,7 +682,7 @@ static int fetch_small(rvb_ctx * ctx)
     RVB_HIP(ctx, hipMemcpyAsync(ctx->small_host, ctx->small.p, kSmallBytes, hipMemcpyDeviceToHost, ctx->stream));
     if (ctx->traced_rays)      // capacity rays * 9 >= 32 entries unless there are fewer than 4 rays
         RVB_HIP(ctx, hipMemcpyAsync(ctx->first_candidates, ctx->candidates.p,
-                                    std::min(sizeof(ctx->first_candidates), (size_t) ctx->traced_rays * 9 * sizeof(rvb_image_candidate)),
+                                    std::min(kFirstCandidates * sizeof(rvb_image_candidate), (size_t) ctx->traced_rays * 9 * sizeof(rvb_image_candidate)),
                                     hipMemcpyDeviceToHost, ctx->stream));
     if (ctx->npairs > 1) {     // per-pair direct paths and time ranges
         ctx->pair_direct_host.resize(ctx->npairs);
@@ -730,7 +745,7 @@ int rvb_get_image_candidates(rvb_ctx * ctx, rvb_image_candidate * out, uint64_t 
     if (capacity < n)
         return fail(ctx, RVB_ERR_CAPACITY, "rvb_get_image_candidates: capacity too small");
     if (n) {
-        if (n <= sizeof(ctx->first_candidates) / sizeof(rvb_image_candidate))
+        if (n <= kFirstCandidates)
             std::memcpy(out, ctx->first_candidates, (size_t) n * sizeof(rvb_image_candidate));     // came with the small block
         else
             RVB_HIP(ctx, hipMemcpy(out, ctx->candidates.p, (size_t) n * sizeof(rvb_image_candidate), hipMemcpyDeviceToHost));
@@ -1171,6 +1186,51 @@ int rvb_copy_to_device(rvb_ctx * ctx, void * d_dst, const void * src, uint64_t b
     if (bytes && (!d_dst || !src)) return fail(ctx, RVB_ERR_INVALID, "rvb_copy_to_device: null pointer");
     RVB_BIND(ctx);
     return staged_copy(ctx, const_cast<void *>(src), d_dst, bytes, false);
+}
+
+int rvb_host_alloc(rvb_ctx * ctx, uint64_t bytes, void ** host_ptr)
+{
+    if (!ctx || !host_ptr) return RVB_ERR_INVALID;
+    RVB_BIND(ctx);
+    *host_ptr = nullptr;
+    RVB_HIP(ctx, hipHostMalloc(host_ptr, bytes ? bytes : 16, hipHostMallocDefault));
+    return RVB_OK;
+}
+
+int rvb_host_free(rvb_ctx * ctx, void * host_ptr)
+{
+    if (!ctx) return RVB_ERR_INVALID;
+    if (!host_ptr) return RVB_OK;
+    RVB_BIND(ctx);
+    RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RVB_HIP(ctx, hipHostFree(host_ptr));
+    return RVB_OK;
+}
+
+int rvb_copy_to_pinned_host_async(rvb_ctx * ctx, void * pinned_dst, const void * d_src, uint64_t bytes)
+{
+    if (!ctx) return RVB_ERR_INVALID;
+    if (bytes && (!pinned_dst || !d_src)) return fail(ctx, RVB_ERR_INVALID, "rvb_copy_to_pinned_host_async: null pointer");
+    if (bytes == 0) return RVB_OK;
+    RVB_BIND(ctx);
+    // Ordered behind what the context's stream holds now, but on a stream of its own: neither the host nor the context's next trace
+    // waits for the link.  The copy itself is the runtime's (a blit kernel on this box: no DMA engine takes it).  Measured at
+    // workload C2, ms per IR in the bench pipeline (profiles/r03_export_variants_n1.txt): no copy 4.51-4.79, this 4.57-4.62, the same
+    // copy issued from a torch side stream when the IR is handed over 4.96, in stream order on the context's own stream 5.90, and
+    // copy kernels of this library's own with 2-512 waves and plain / nt / sc1 / sc0 sc1 stores 4.83-5.97 — stores to host memory
+    // from a few long-lived waves slow every other kernel's memory traffic down for as long as they last.
+    RVB_HIP(ctx, hipEventRecord(ctx->export_ready, ctx->stream));
+    RVB_HIP(ctx, hipStreamWaitEvent(ctx->export_stream, ctx->export_ready, 0));
+    RVB_HIP(ctx, hipMemcpyAsync(pinned_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->export_stream));
+    return RVB_OK;
+}
+
+int rvb_synchronize_exports(rvb_ctx * ctx)
+{
+    if (!ctx) return RVB_ERR_INVALID;
+    RVB_BIND(ctx);
+    RVB_HIP(ctx, hipStreamSynchronize(ctx->export_stream));
+    return RVB_OK;
 }
 
 // ---- fused impulse-response stage ----------------------------------------------------------------

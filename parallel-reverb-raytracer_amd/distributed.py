@@ -106,7 +106,8 @@ def begin_ir(tracer, mic, source, nreflections, air, ray_offset=0):
 
 def generate_ir(tracer, mic, source, nreflections, air, speakers_dir=None, speakers_coeff=None, sample_rate=44100.0,
                 trim_predelay=True, mode=capi.IR_FAST, rank=0, world=1, ray_offset=0, device="cpu",
-                which=capi.IR_ALL, remove_direct=False, on_stage=None, begun=False, model=None, collectives=None, defer=False):
+                which=capi.IR_ALL, remove_direct=False, on_stage=None, begun=False, model=None, collectives=None, defer=False,
+                host_out=None):
     """One impulse response from the rays already set on `tracer`.  Returns (hist tensor
     [nchannels][8][nbins] — identical on every rank —, info dict).
 
@@ -119,6 +120,11 @@ def generate_ir(tracer, mic, source, nreflections, air, speakers_dir=None, speak
     begun=True: begin_ir(tracer, ...) has already enqueued this IR's trace.  A caller with two contexts per GPU
     calls begin_ir on the second before generate_ir(..., begun=True) on the first, so that one IR's trace (VALU-bound)
     runs beside the other's record grouping, binning, host work and collectives (IrPipeline below).
+
+    host_out(shape) -> pinned host tensor: the finished histogram is also copied there (info["host"]) — enqueued behind the binning
+    (behind the all-reduce with collectives) on the tracer's export stream, so neither the host nor the tracer's next trace waits for
+    the link; info["host"] is complete after tracer.synchronize_exports() (or a device-wide synchronisation), and the caller keeps
+    `hist` alive until then.
 
     defer=True: returns (hist, info, finish) as soon as the binning is ENQUEUED; finish() waits for it (and runs the all-reduce).
     A caller that finishes several IRs enqueues all their binning stages first, so that they run side by side instead of each
@@ -172,6 +178,13 @@ def generate_ir(tracer, mic, source, nreflections, air, speakers_dir=None, speak
     if contributes:                                      # (the tracer's stream waits for torch's zero fill by an event)
         tracer.ir_accumulate_tensor(predelay, sample_rate, nbins, mode, hist)
     info = {"nbins": nbins, "predelay": predelay, "images": int(images.shape[0]), "max_time": hi}
+    host = host_out(tuple(hist.shape)) if host_out is not None else None
+    if host is not None:
+        info["host"] = host
+        if not collectives and hasattr(tracer, "export_tensor_to_host"):
+            if not contributes:                          # (nothing was enqueued on the tracer's stream: order the copy behind torch's zero fill)
+                tracer.ir_accumulate_wait_for_torch()
+            tracer.export_tensor_to_host(hist, host)     # stream order: behind the binning
 
     def finish():
         if on_stage:
@@ -179,6 +192,12 @@ def generate_ir(tracer, mic, source, nreflections, air, speakers_dir=None, speak
         tracer.synchronize()
         if collectives:
             dist.all_reduce(hist, op=dist.ReduceOp.SUM)  # RCCL over xGMI: [channels][8][nbins] floats
+        if host is not None and (collectives or not hasattr(tracer, "export_tensor_to_host")):
+            if hist.is_cuda and hasattr(tracer, "export_tensor_to_host"):
+                tracer.ir_accumulate_wait_for_torch()    # the all-reduce ran on torch's stream: the tracer's stream waits for it by an event
+                tracer.export_tensor_to_host(hist, host)
+            else:
+                host.copy_(hist)
 
     if defer:
         return hist, info, finish
