@@ -1373,35 +1373,59 @@ int rvb_ir_accumulate(rvb_ctx * ctx, float predelay, float sample_rate, uint64_t
         ctx->end_timing();
     } else if (mode == RVB_IR_EXACT) {
         const uint64_t n = ndiffuse + nimages;
-        if (n >= (1ull << 32)) return fail(ctx, RVB_ERR_CAPACITY, "rvb_ir_accumulate: too many impulses for exact mode");
+        if (n >= (1ull << 31)) return fail(ctx, RVB_ERR_CAPACITY, "rvb_ir_accumulate: too many impulses for exact mode");
+        if (nbins >= 0x7FFFFFF0ull) return fail(ctx, RVB_ERR_CAPACITY, "rvb_ir_accumulate: too many bins for exact mode");
         ctx->flat_host = nullptr;                 // keys_a / vals_a are rewritten below: a pending rvb_flatten size query is void
-        int rc = ensure_sort_buffers(ctx, n);
-        if (rc != RVB_OK) return rc;
-        if (nbins >= 0xFFFFFFFFull) return fail(ctx, RVB_ERR_CAPACITY, "rvb_ir_accumulate: too many bins for exact mode");
-        // keys are bins, nbins itself marks "adds nothing": key_bits_for(nbins) bits cover 0 .. nbins
-        const int bits = key_bits_for(nbins);
-        const uint32_t sentinel = (uint32_t) nbins;
+        const char * split_env = getenv("RVB_HRTF_SPLIT_EARS");     // measurement / test switch (read per call): one list per ear, as in round 2
+        const bool split_ears = split_env && split_env[0] == '1';
         ctx->begin_timing("exact_mode");
-        // speaker channels keep the input time (kernel.cpp:530-533): one sorted list serves them all; the two ears of the
-        // HRTF model shift the time differently (kernel.cpp:616-622) and get a list each
-        const uint32_t lists = m.hrtf ? m.nchannels : 1u;
-        RVB_HIP(ctx, ctx->bin_starts.ensure(nbins * 8));          // starts, then ends
-        for (uint32_t ch = 0; ch < lists; ++ch) {
-            rvb_launch_bin_keys(m, ch, ir_diffuse(ctx), ndiffuse, 0, predelay, sample_rate, sentinel,
-                                ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), ctx->stream);
-            rvb_launch_bin_keys(m, ch, ctx->images.as<rvb_impulse>(), nimages, ndiffuse, predelay, sample_rate, sentinel,
-                                ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), ctx->stream);
-            if (own_sort_enabled()) {
-                const int rc = own_sort(ctx, ctx->keys_a.as<uint32_t>(), 0u, n, 0, bits, ctx->keys_b.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), true);
-                if (rc != RVB_OK) return rc;
-            } else {
-                rvb_sort_pairs(ctx->sort_temp.p, ctx->sort_temp.cap, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(),
-                               ctx->vals_a.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), n, bits, ctx->stream);
+        if (m.hrtf && !split_ears) {
+            // the two ears shift the arrival time differently (kernel.cpp:616-622): one pass keys every impulse for both ears into ONE
+            // list of 2 n entries, one radix sort orders it, one launch folds both ears (stream_kernels.hip, bin_keys_hrtf_kernel)
+            int rc = ensure_sort_buffers(ctx, 2 * n);
+            if (rc != RVB_OK) return rc;
+            const uint64_t nkeys = 2 * (nbins + 1);
+            const int bits = key_bits_for(nkeys - 1);
+            RVB_HIP(ctx, ctx->bin_starts.ensure(nkeys * 8));       // starts, then ends
+            rvb_launch_bin_keys_hrtf(m, ir_diffuse(ctx), ndiffuse, 0, n, predelay, sample_rate, (uint32_t) nbins,
+                                     ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), ctx->stream);
+            rvb_launch_bin_keys_hrtf(m, ctx->images.as<rvb_impulse>(), nimages, ndiffuse, n, predelay, sample_rate, (uint32_t) nbins,
+                                     ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), ctx->stream);
+            // (explicit values — the two halves carry the same impulse numbers — and always rocPRIM's sort: RVB_SORT=own takes identity values only.
+            // Values derived from the entry's position by a transform iterator instead of an array: 1.52 -> 1.58 ms, and 0.85 -> 0.88 ms for the
+            // one-list speaker form; rocPRIM's first pass reads an array faster than it evaluates an iterator.)
+            rvb_sort_pairs(ctx->sort_temp.p, ctx->sort_temp.cap, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(),
+                           ctx->vals_a.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), 2 * n, bits, ctx->stream);
+            RVB_HIP(ctx, hipMemsetAsync(ctx->bin_starts.p, 0xFF, nkeys * 4, ctx->stream));
+            rvb_launch_bin_starts(ctx->keys_b.as<uint32_t>(), 2 * n, nkeys, ctx->bin_starts.as<uint32_t>(), ctx->bin_starts.as<uint32_t>() + nkeys, ctx->stream);
+            rvb_launch_ordered_sum_hrtf(m, ir_diffuse(ctx), ndiffuse, ctx->images.as<rvb_impulse>(), ctx->vals_b.as<uint32_t>(),
+                                        ctx->bin_starts.as<uint32_t>(), ctx->bin_starts.as<uint32_t>() + nkeys, nbins, hist, ctx->stream);
+        } else {
+            int rc = ensure_sort_buffers(ctx, n);
+            if (rc != RVB_OK) return rc;
+            // keys are bins, nbins itself marks "adds nothing": key_bits_for(nbins) bits cover 0 .. nbins
+            const int bits = key_bits_for(nbins);
+            const uint32_t sentinel = (uint32_t) nbins;
+            // speaker channels keep the input time (kernel.cpp:530-533): one sorted list serves them all
+            const uint32_t lists = m.hrtf ? m.nchannels : 1u;
+            RVB_HIP(ctx, ctx->bin_starts.ensure(nbins * 8));          // starts, then ends
+            for (uint32_t ch = 0; ch < lists; ++ch) {
+                rvb_launch_bin_keys(m, ch, ir_diffuse(ctx), ndiffuse, 0, predelay, sample_rate, sentinel,
+                                    ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), ctx->stream);
+                rvb_launch_bin_keys(m, ch, ctx->images.as<rvb_impulse>(), nimages, ndiffuse, predelay, sample_rate, sentinel,
+                                    ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), ctx->stream);
+                if (own_sort_enabled()) {
+                    const int rc2 = own_sort(ctx, ctx->keys_a.as<uint32_t>(), 0u, n, 0, bits, ctx->keys_b.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), true);
+                    if (rc2 != RVB_OK) return rc2;
+                } else {
+                    rvb_sort_pairs(ctx->sort_temp.p, ctx->sort_temp.cap, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(),
+                                   ctx->vals_a.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), n, bits, ctx->stream);
+                }
+                RVB_HIP(ctx, hipMemsetAsync(ctx->bin_starts.p, 0xFF, nbins * 4, ctx->stream));
+                rvb_launch_bin_starts(ctx->keys_b.as<uint32_t>(), n, nbins, ctx->bin_starts.as<uint32_t>(), ctx->bin_starts.as<uint32_t>() + nbins, ctx->stream);
+                rvb_launch_ordered_sum(m, ch, m.hrtf ? 1u : m.nchannels, ir_diffuse(ctx), ndiffuse, ctx->images.as<rvb_impulse>(), nimages,
+                                       ctx->vals_b.as<uint32_t>(), ctx->bin_starts.as<uint32_t>(), ctx->bin_starts.as<uint32_t>() + nbins, n, nbins, hist, ctx->stream);
             }
-            RVB_HIP(ctx, hipMemsetAsync(ctx->bin_starts.p, 0xFF, nbins * 4, ctx->stream));
-            rvb_launch_bin_starts(ctx->keys_b.as<uint32_t>(), n, nbins, ctx->bin_starts.as<uint32_t>(), ctx->bin_starts.as<uint32_t>() + nbins, ctx->stream);
-            rvb_launch_ordered_sum(m, ch, m.hrtf ? 1u : m.nchannels, ir_diffuse(ctx), ndiffuse, ctx->images.as<rvb_impulse>(), nimages,
-                                   ctx->vals_b.as<uint32_t>(), ctx->bin_starts.as<uint32_t>(), ctx->bin_starts.as<uint32_t>() + nbins, n, nbins, hist, ctx->stream);
         }
         ctx->end_timing();
     } else {

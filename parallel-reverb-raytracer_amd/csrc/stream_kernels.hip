@@ -38,6 +38,7 @@ struct ModelDev {
     v3 bx, by, bz;          // the listener's basis of kernel.cpp:538-549 — it depends on (pointing, up) only, so it is computed once
                             // on the host with the same operations (rvb_math.h is shared) instead of once per impulse
     v3 ear[2];              // kernel.cpp:599-603
+    bool exact_rows;        // measurement / test switch RVB_HRTF_EXACT_ROWS=1: every table row through the binary64 atan2 (angle_deg)
 };
 
 // reference kernel.cpp:537-549
@@ -68,6 +69,8 @@ ModelDev make_model(const AttenuationModel & m)
     const float width = 0.1f;                                   // kernel.cpp:597
     d.ear[0] = transform3(d.pointing, d.up, mk3(-width, 0.0f, 0.0f)) + d.mic;
     d.ear[1] = transform3(d.pointing, d.up, mk3(width, 0.0f, 0.0f)) + d.mic;
+    const char * e = getenv("RVB_HRTF_EXACT_ROWS");          // (read per launch: a test flips it inside one process)
+    d.exact_rows = e && e[0] == '1';
     return d;
 }
 
@@ -87,21 +90,46 @@ __device__ __forceinline__ v3 to_listener(const ModelDev & m, v3 d)
     return mk3(dot3(m.bx, d), dot3(m.by, d), dot3(m.bz, d));
 }
 
-__device__ __forceinline__ int64_t hrtf_row(const ModelDev & m, v3 pos)
+// Table row = a * 180 + e with a = (long) (degrees(azimuth) + 180) % 360, e = 90 - (long) degrees(elevation) (kernel.cpp:569-584).
+// Only the INTEGER parts of the two angles in degrees matter.  The oracle's atan2 is the correctly rounded binary32 value
+// (evaluated in binary64: ~150 double-precision instructions per call); here the angle is first taken with the binary32 atan2f
+// (~40 instructions) and the binary64 evaluation is kept for the cases where that could change the integer part:
+//   deg_fast and deg_exact differ by at most 57.3 * |atan2f - atan2| + two roundings of a value <= 360
+//   <= 57.3 * 1.5e-6 (atan2f: 6 ulp of pi at most, OpenCL / ocml accuracy) + 2 * 1.6e-5 < 1.2e-4 degrees,
+// so an angle that is farther than kAngleMargin = 2e-3 degrees from every integer truncates to the same integer either way
+// (about 0.4 % of the angles are nearer and take the binary64 path; NaN compares false and takes it too).
+// tests/test_gpu_parity.py holds whole traces' rows against the always-exact evaluation (RVB_HRTF_EXACT_ROWS=1).
+#define RVB_DEG_PER_RAD 57.295779513082320877f
+__device__ __forceinline__ float angle_deg(float y, float x, float offset, bool always_exact)
 {
-    const v3 t = to_listener(m, normalize3(pos - m.mic));
-    const float az = atan2_cr(t.x, t.z);
-    const float el = atan2_cr(t.y, sqrtf(t.x * t.x + t.z * t.z));
-    int64_t a = (int64_t) (az * 57.295779513082320877f + 180);
+    float deg = atan2f(y, x) * RVB_DEG_PER_RAD + offset;
+    const float kAngleMargin = 2e-3f;
+    const bool sure = fabsf(deg - rintf(deg)) > kAngleMargin;
+    if (!sure || always_exact)
+        deg = atan2_cr(y, x) * RVB_DEG_PER_RAD + offset;        // the reference's operations on the correctly rounded angle
+    return deg;
+}
+
+__device__ __forceinline__ int64_t row_of(float az_deg_plus_180, float el_deg)
+{
+    int64_t a = (int64_t) az_deg_plus_180;
     a %= 360;
-    int64_t e = (int64_t) (el * 57.295779513082320877f);
+    int64_t e = (int64_t) el_deg;
     e = 90 - e;
     return a * 180 + e;     // e == 180 runs into the next azimuth row (quirk Q5); row 360*180 is zero padding
 }
 
-// The same row for a quad that shares one impulse: azimuth and elevation are both atan2(y, x) of different arguments, so the
-// even lanes evaluate the azimuth and the odd lanes the elevation with ONE call (it is ~150 double-precision instructions),
-// then swap by DPP.  Same operations on the same operands as hrtf_row.
+__device__ __forceinline__ int64_t hrtf_row(const ModelDev & m, v3 pos)
+{
+    const v3 t = to_listener(m, normalize3(pos - m.mic));
+    const float az = angle_deg(t.x, t.z, 180.0f, m.exact_rows);
+    const float el = angle_deg(t.y, sqrtf(t.x * t.x + t.z * t.z), 0.0f, m.exact_rows);
+    return row_of(az, el);
+}
+
+// The same row for two neighbouring lanes that share one impulse (a quad of attenuate_kernel, the two lanes of a bin in
+// ordered_sum_hrtf_kernel): azimuth and elevation are both atan2(y, x) of different arguments, so the even lane evaluates the
+// azimuth and the odd lane the elevation with ONE call, then they swap by DPP.  Same operations on the same operands as hrtf_row.
 template <int CTRL> __device__ __forceinline__ float qdpp_f(float v);
 __device__ __forceinline__ int64_t hrtf_row_quad(const ModelDev & m, v3 pos, uint32_t q)
 {
@@ -109,14 +137,9 @@ __device__ __forceinline__ int64_t hrtf_row_quad(const ModelDev & m, v3 pos, uin
     const bool odd = q & 1u;
     const float y = odd ? t.y : t.x;
     const float x = odd ? sqrtf(t.x * t.x + t.z * t.z) : t.z;
-    const float deg = atan2_cr(y, x) * 57.295779513082320877f;
+    const float deg = angle_deg(y, x, odd ? 0.0f : 180.0f, m.exact_rows);
     const float other = qdpp_f<0xB1>(deg);                     // quad_perm [1,0,3,2]: the pair lane's angle
-    const float az_deg = odd ? other : deg, el_deg = odd ? deg : other;
-    int64_t a = (int64_t) (az_deg + 180);
-    a %= 360;
-    int64_t e = (int64_t) el_deg;
-    e = 90 - e;
-    return a * 180 + e;
+    return row_of(odd ? other : deg, odd ? deg : other);
 }
 
 // reference kernel.cpp:616-622: arrival-time shift of one ear
@@ -419,6 +442,34 @@ __global__ __launch_bounds__(256) void bin_keys_kernel(ModelDev m, uint32_t ch, 
     }
 }
 
+// HRTF model: the two ears shift the arrival time differently (kernel.cpp:616-622), so each ear has its own bin per impulse.  Both
+// keys come from ONE pass over the impulses, into ONE list of 2 n entries that one radix sort orders: ear e's entry of impulse j
+// sits at e * n + j and carries key e * (nbins + 1) + bin (its sentinel: e * (nbins + 1) + nbins), so the sorted list is ear 0's
+// bins, ear 0's silent impulses, ear 1's bins, ear 1's silent impulses — each run in impulse order (the sort is stable).
+__global__ __launch_bounds__(256) void bin_keys_hrtf_kernel(ModelDev m, const rvb_impulse * __restrict__ in, uint64_t count, uint64_t index_base,
+                                                            uint64_t n, float predelay, float sample_rate, uint32_t nbins,
+                                                            uint32_t * __restrict__ keys, uint32_t * __restrict__ values)
+{
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t) gridDim.x * blockDim.x) {
+        const float4 * r = reinterpret_cast<const float4 *>(in + i);
+        const float4 v0 = r[0], v1 = r[1], p = r[2];
+        const float time = r[3].x;
+        const bool nonzero = v0.x != 0.0f || v0.y != 0.0f || v0.z != 0.0f || v0.w != 0.0f
+                          || v1.x != 0.0f || v1.y != 0.0f || v1.z != 0.0f || v1.w != 0.0f;
+        uint32_t k0 = nbins, k1 = nbins;                      // (a zero-volume impulse adds nothing: bin_keys_kernel)
+        if (nonzero) {
+            const v3 pos = mk3(p.x, p.y, p.z);
+            k0 = min(time_bin(hrtf_time(m, 0, pos, time), predelay, sample_rate), nbins);
+            k1 = min(time_bin(hrtf_time(m, 1, pos, time), predelay, sample_rate), nbins);
+        }
+        const uint64_t j = index_base + i;
+        keys[j] = k0;
+        keys[n + j] = nbins + 1u + k1;
+        values[j] = (uint32_t) j;
+        values[n + j] = (uint32_t) j;
+    }
+}
+
 // Where each bin's run starts in the sorted key list: starts[key] = first position of that key (entries of absent keys keep
 // the caller's 0xFFFFFFFF fill).  One coalesced pass over the keys replaces a 23-step binary search per bin — 19 M dependent
 // random reads at workload C2, which made the summation kernel fetch 3 GB for 0.5 GB of impulses.
@@ -504,6 +555,57 @@ __global__ __launch_bounds__(64) void ordered_sum_kernel(ModelDev m, uint32_t fi
 #pragma unroll
         for (int b = 0; b < 4; ++b)
             hist[((uint64_t) (first_channel + c) * 8 + half * 4 + b) * nbins + bin] = sum[c][b];
+}
+
+// The HRTF model's ordered sum, both ears in ONE launch over the combined list of bin_keys_hrtf_kernel: two lanes per (ear, bin) —
+// the even lane folds bands 0-3 and evaluates the azimuth, the odd lane bands 4-7 and the elevation (hrtf_row_quad: one atan2 per
+// lane and impulse instead of two, the binary32 one unless the integer part of an angle is in doubt).
+__global__ __launch_bounds__(64) void ordered_sum_hrtf_kernel(ModelDev m, const rvb_impulse * __restrict__ diffuse, uint64_t ndiffuse,
+                                                              const rvb_impulse * __restrict__ images, const uint32_t * __restrict__ values,
+                                                              const uint32_t * __restrict__ starts, const uint32_t * __restrict__ ends,
+                                                              uint64_t nbins, float * __restrict__ hist)
+{
+    const uint64_t t = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t slot = t >> 1;                             // (ear, bin)
+    const uint32_t half = (uint32_t) t & 1u;
+    if (slot >= 2 * nbins)
+        return;
+    const uint32_t ear = slot >= nbins ? 1u : 0u;
+    const uint64_t bin = slot - (uint64_t) ear * nbins;
+    const uint64_t key = (uint64_t) ear * (nbins + 1) + bin;
+    const uint64_t lo = starts[key];
+    if (lo == 0xFFFFFFFFull)
+        return;                               // nothing lands in this bin: the histogram keeps what it holds (both lanes of the pair leave)
+    float sum[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+        sum[b] = hist[((uint64_t) ear * 8 + half * 4 + b) * nbins + bin];
+    const uint64_t hi = ends[key];
+    const float * table = m.table + (uint64_t) ear * (360 * 180 + 1) * 8 + half * 4;
+    for (uint64_t k = lo; k < hi; k += SUM_UNROLL) {
+        float4 v[SUM_UNROLL], p[SUM_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SUM_UNROLL; ++u) {
+            const uint64_t kk = k + u < hi ? k + u : lo;
+            const uint64_t idx = values[kk];
+            const rvb_impulse * imp = idx < ndiffuse ? diffuse + idx : images + (idx - ndiffuse);
+            const float4 * r = reinterpret_cast<const float4 *>(imp);
+            v[u] = r[half];
+            p[u] = r[2];
+        }
+#pragma unroll
+        for (int u = 0; u < SUM_UNROLL; ++u) {
+            if (k + u >= hi) break;           // (the two lanes of a bin agree: the DPP exchange below always finds its partner)
+            const float4 tb = *reinterpret_cast<const float4 *>(table + (uint64_t) hrtf_row_quad(m, mk3(p[u].x, p[u].y, p[u].z), half) * 8);
+            sum[0] += v[u].x * tb.x;
+            sum[1] += v[u].y * tb.y;
+            sum[2] += v[u].z * tb.z;
+            sum[3] += v[u].w * tb.w;
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+        hist[((uint64_t) ear * 8 + half * 4 + b) * nbins + bin] = sum[b];
 }
 
 __global__ __launch_bounds__(256) void flat_keys_kernel(const rvb_attenuated_impulse * __restrict__ in, uint64_t n, float sample_rate,
@@ -612,6 +714,23 @@ void rvb_launch_bin_keys(const AttenuationModel & m, uint32_t channel, const rvb
     if (n == 0) return;
     hipLaunchKernelGGL(bin_keys_kernel, dim3(stream_blocks(n, 256)), dim3(256), 0, s, make_model(m), channel, in, n,
                        index_base, predelay, sample_rate, sentinel, keys, values);
+}
+
+void rvb_launch_bin_keys_hrtf(const AttenuationModel & m, const rvb_impulse * in, uint64_t count, uint64_t index_base, uint64_t n,
+                              float predelay, float sample_rate, uint32_t nbins, uint32_t * keys, uint32_t * values, hipStream_t s)
+{
+    if (count == 0) return;
+    hipLaunchKernelGGL(bin_keys_hrtf_kernel, dim3(stream_blocks(count, 256)), dim3(256), 0, s, make_model(m), in, count, index_base, n,
+                       predelay, sample_rate, nbins, keys, values);
+}
+
+void rvb_launch_ordered_sum_hrtf(const AttenuationModel & m, const rvb_impulse * diffuse, uint64_t ndiffuse, const rvb_impulse * images,
+                                 const uint32_t * sorted_values, const uint32_t * starts, const uint32_t * ends, uint64_t nbins, float * hist,
+                                 hipStream_t s)
+{
+    if (nbins == 0) return;
+    hipLaunchKernelGGL(ordered_sum_hrtf_kernel, dim3((unsigned) ((4 * nbins + 63) / 64)), dim3(64), 0, s, make_model(m), diffuse, ndiffuse,
+                       images, sorted_values, starts, ends, nbins, hist);
 }
 
 void rvb_launch_ordered_sum(const AttenuationModel & m, uint32_t first_channel, uint32_t nchannels, const rvb_impulse * diffuse,

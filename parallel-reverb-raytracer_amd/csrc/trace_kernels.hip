@@ -814,20 +814,40 @@ __device__ __forceinline__ lds_float4_ptr stage_surfaces(const TraceArgs & a, ui
 }
 
 // LANES = 4: quad lane c stores chunk c.  LANES = 2: lane c of the pair stores chunks c and c + 2.
-template <bool SURF_LDS, int LANES = 4>
+// COLD (the two-lane kernel): what only the shading step touches — the lane's four band volumes and the path length so far — lives
+// in LDS between bounces ([5][64] words behind the surface table, one column per lane) instead of in five registers that the
+// compiler would otherwise keep through every node and leaf step: with them the kernel fits the 72-register budget of seven
+// waves per SIMD without scratch spills (the compiler's own choice at that budget spills two values the LEAF step reloads).
+// Measured at workload C2 (round 3, profiles/r03_pair_cold_state_n1.txt): with COLD the group kernel needs 72 registers and no
+// scratch, all 6 250 waves of two 100 k-ray traces are resident at once (80 registers: 6 144 slots, and the 106 waves that start
+// when the first ones finish run a whole 128-bounce chain almost alone: 196 608 rays 4.97 ms, 200 000 rays 6.15 ms), and the launch
+// takes 5.36 instead of 6.15 ms.  In the bench pipeline it LOSES (4.81 against 4.59 ms per IR): the other group's sort, shadow and
+// binning kernels used to run in that long thin tail and now stretch by what the path kernel gained (chain per context 16.7 against
+// 16.6 ms).  Off by default; -DRVB_PAIR_COLD=1 for callers whose path launches run alone.
+#ifndef RVB_PAIR_COLD
+#define RVB_PAIR_COLD 0
+#endif
+__device__ __forceinline__ uint32_t lane_id_here()
+{
+    uint32_t lane;      // (volatile: recomputed where it is used instead of being kept in a register across the traversal loop)
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    return lane;
+}
+template <bool SURF_LDS, int LANES = 4, bool COLD = false>
 struct PathJob {
     const TraceArgs & a;
     uint32_t ray;                        // < 2^32 / 9 (rvb_trace checks)
     uint32_t c;
     v3 o, d;
-    float distance;
-    float4 vol;                          // lane 0 (and 2): bands 0-3, lane 1 (and 3): bands 4-7 — the chunk the lane stores
+    float distance;                      // (COLD: in LDS)
+    float4 vol;                          // lane 0 (and 2): bands 0-3, lane 1 (and 3): bands 4-7 — the chunk the lane stores (COLD: in LDS)
     uint32_t index;
     bool alive;
     lds_float4_ptr surf_lds;             // the surface table staged in LDS (stage_surfaces); unused when !SURF_LDS
     uint32_t pair_tag;                   // (source, microphone) pair of this ray + 1: what marks its work records as valid
     uint32_t skip;                       // own-plane subtree of the triangle the current segment starts on (TriShade, bvh.h)
     bool unit;                           // the ray's direction has unit length (the own-plane rule is derived for |d| = 1)
+    float * cold;                        // COLD: this workgroup's [5][64] words in LDS
 
     __device__ __forceinline__ uint32_t skip_ref() const { return skip; }
     __device__ __forceinline__ bool next(v3 & o_, v3 & d_, float & tmax)
@@ -855,6 +875,12 @@ struct PathJob {
         float4 sp;
         if (SURF_LDS) sp = lds_load4(surf_lds, 4 * surface + half);
         else sp = reinterpret_cast<const float4 *>(a.scene.surfaces + surface)[half];
+        float * mine = nullptr;
+        if (COLD) {
+            mine = cold + lane_id_here();
+            vol = make_float4(mine[0], mine[64], mine[128], mine[192]);
+            distance = mine[256];
+        }
         const v3 p = o + d * h.t;                                    // kernel.cpp:459
         const float new_dist = distance + h.t;                       // kernel.cpp:460
         vol = make_float4(-vol.x * sp.x, -vol.y * sp.y, -vol.z * sp.z, -vol.w * sp.w);   // kernel.cpp:461
@@ -889,9 +915,13 @@ struct PathJob {
 #if RVB_PROBE_NO_STORES
         }
 #endif
+        if (COLD) {
+            mine[0] = vol.x; mine[64] = vol.y; mine[128] = vol.z; mine[192] = vol.w;
+            mine[256] = new_dist;
+        }
         d = reflect3(normal, d);                                     // kernel.cpp:492-499
         o = p;
-        distance = new_dist;
+        if (!COLD) distance = new_dist;
         ++index;
     }
 };
@@ -933,7 +963,7 @@ __global__ __launch_bounds__(WAVE, WAVES) void path_kernel(TraceArgs a)
     const float4 d4 = a.directions[local];
     const float len2 = d4.x * d4.x + d4.y * d4.y + d4.z * d4.z;
     PathJob<SURF_LDS> job = {a, (uint32_t) ray, threadIdx.x & 3u, source, mk3(d4.x, d4.y, d4.z), 0.0f,
-                   make_float4(1.0f, 1.0f, 1.0f, 1.0f), 0u, true, surf_lds, pair + 1u, RVB_BVH_EMPTY, fabsf(len2 - 1.0f) < 1e-3f};
+                   make_float4(1.0f, 1.0f, 1.0f, 1.0f), 0u, true, surf_lds, pair + 1u, RVB_BVH_EMPTY, fabsf(len2 - 1.0f) < 1e-3f, nullptr};
 #if RVB_PATH_JOBS == 2
 #if RVB_LDS_NODES
     traverse_jobs_vote(a.scene, stack_lds + q, job, lds_nodes);
@@ -998,8 +1028,14 @@ __device__ __forceinline__ void path_pair_body(const TraceArgs & a, const uint32
     }
     const float4 d4 = a.directions[local];
     const float len2 = d4.x * d4.x + d4.y * d4.y + d4.z * d4.z;
-    PathJob<SURF_LDS, 2> job = {a, (uint32_t) ray, threadIdx.x & 1u, source, mk3(d4.x, d4.y, d4.z), 0.0f,
-                   make_float4(1.0f, 1.0f, 1.0f, 1.0f), 0u, true, surf_lds, pair + 1u, RVB_BVH_EMPTY, fabsf(len2 - 1.0f) < 1e-3f};
+    // the cold words sit behind the stack and the surface table (rvb_pair_lds_bytes)
+    float * cold = reinterpret_cast<float *>(stack_lds + a.stack_entries * PAIRS_PER_BLOCK + 16u * a.lds_surfaces + (RVB_LDS_NODES * 16u));
+    if (RVB_PAIR_COLD) {
+        cold[threadIdx.x] = 1.0f; cold[64 + threadIdx.x] = 1.0f; cold[128 + threadIdx.x] = 1.0f; cold[192 + threadIdx.x] = 1.0f;
+        cold[256 + threadIdx.x] = 0.0f;
+    }
+    PathJob<SURF_LDS, 2, RVB_PAIR_COLD != 0> job = {a, (uint32_t) ray, threadIdx.x & 1u, source, mk3(d4.x, d4.y, d4.z), 0.0f,
+                   make_float4(1.0f, 1.0f, 1.0f, 1.0f), 0u, true, surf_lds, pair + 1u, RVB_BVH_EMPTY, fabsf(len2 - 1.0f) < 1e-3f, cold};
 #if RVB_LDS_NODES
     traverse_pairs_vote(a.scene, stack_lds + q, job, lds_nodes);
 #else
@@ -1443,6 +1479,13 @@ static size_t quad_kernel_lds_bytes(const TraceArgs & a)
     return a.stack_entries * QUADS_PER_BLOCK * sizeof(uint32_t) + (size_t) a.lds_surfaces * sizeof(rvb_surface) + RVB_LDS_NODES * 64u;
 }
 
+// LDS of the two-lane path kernel's single-wave workgroup: stack, surface table, (experiment: top nodes), the lanes' cold words
+static size_t rvb_pair_lds_bytes(const TraceArgs & a)
+{
+    return a.stack_entries * PAIRS_PER_BLOCK * sizeof(uint32_t) + (size_t) a.lds_surfaces * sizeof(rvb_surface) + RVB_LDS_NODES * 64u
+           + (RVB_PAIR_COLD ? 5u * WAVE * sizeof(float) : 0u);
+}
+
 uint32_t rvb_lds_surfaces(uint32_t stack_entries, uint64_t nsurfaces)
 {
     // 8 waves/SIMD = 32 single-wave workgroups per CU must still fit in the CU's 160 KiB of LDS
@@ -1474,7 +1517,7 @@ void rvb_launch_path(const TraceArgs & a, hipStream_t s)
     if (a.nrays == 0) return;
     if (a.path_lanes == 2) {
         const unsigned blocks = (unsigned) ((a.nrays + PAIRS_PER_BLOCK - 1) / PAIRS_PER_BLOCK);
-        const size_t lds = a.stack_entries * PAIRS_PER_BLOCK * sizeof(uint32_t) + (size_t) a.lds_surfaces * sizeof(rvb_surface) + RVB_LDS_NODES * 64u;
+        const size_t lds = rvb_pair_lds_bytes(a);
         if (a.lds_surfaces) hipLaunchKernelGGL(path_pair_kernel<true>, dim3(blocks), dim3(WAVE), lds, s, a);
         else hipLaunchKernelGGL(path_pair_kernel<false>, dim3(blocks), dim3(WAVE), lds, s, a);
         return;
@@ -1504,7 +1547,7 @@ void rvb_launch_path_group(const TraceArgs * traces, uint32_t count, hipStream_t
     for (uint32_t k = count; k < RVB_MAX_GROUP; ++k) g.trace[k] = traces[0];
     // (the caller checked: every trace has the same stack depth and the same number of surfaces staged in LDS)
     const TraceArgs & a = traces[0];
-    const size_t lds = a.stack_entries * PAIRS_PER_BLOCK * sizeof(uint32_t) + (size_t) a.lds_surfaces * sizeof(rvb_surface) + RVB_LDS_NODES * 64u;
+    const size_t lds = rvb_pair_lds_bytes(a);
     if (a.lds_surfaces) hipLaunchKernelGGL(path_pair_group_kernel<true>, dim3(blocks), dim3(WAVE), lds, s, g);
     else hipLaunchKernelGGL(path_pair_group_kernel<false>, dim3(blocks), dim3(WAVE), lds, s, g);
 }

@@ -533,3 +533,58 @@ def test_trace_group_one_launch_for_three_contexts_equals_three_traces(ctx):
     finally:
         for c in others:
             c.close()
+
+
+def test_c5_hrtf_rows_by_binary32_atan2_and_the_two_ear_list_equal_the_always_exact_evaluation(ctx):
+    """The HRTF table row of an impulse needs only the INTEGER parts of two angles in degrees; the kernels take them from the binary32
+    atan2f and fall back to the correctly rounded (binary64) evaluation when an angle lies within 2e-3 degrees of an integer
+    (stream_kernels.hip, angle_deg).  At BASELINE config C5's full size — every impulse of 100 000 rays x 128 bounces, two pairs —
+    the materialised `hrtf` kernel of both ears and the exact-mode [2][8][nbins] histogram (one combined two-ear list, one sort, one
+    fold) must give the bytes of the always-exact evaluation with one sorted list per ear (RVB_HRTF_EXACT_ROWS=1,
+    RVB_HRTF_SPLIT_EARS=1: the round-2 path, which the oracle-chain tests above pin)."""
+    import os
+    import torch
+    from parallel_reverb_raytracer_amd import capi
+    scene, _ = scenes.concert_hall(30000)
+    src, mic = scenes.source_mic_pairs(64, seed=0)
+    table = scenes.hrtf_synthetic_table()
+    nrays, nrefl = 100000, 128
+    ctx.set_scene(scene)
+    ctx.set_directions(scenes.sphere_directions(nrays, seed=1))
+    saved = {k: os.environ.get(k) for k in ("RVB_HRTF_EXACT_ROWS", "RVB_HRTF_SPLIT_EARS")}
+
+    def switches(on):
+        for k in saved:
+            if on:
+                os.environ[k] = "1"
+            else:
+                os.environ.pop(k, None)
+
+    try:
+        for pair in (31, 5):
+            facing = src[pair] - mic[pair]
+            facing = facing / np.linalg.norm(facing)
+            ctx.trace(mic[pair], src[pair], nrefl, AIR_COEFFICIENTS)
+            d_in, n = ctx.diffuse_device()
+            images = capi.merge_images(ctx.get_image_candidates(), ctx.get_direct(), False)
+            out = torch.empty(n * 64, dtype=torch.uint8, device="cuda")
+            got = {}
+            for exact in (False, True):
+                switches(exact)
+                crcs = []
+                for ch in (0, 1):
+                    ctx.attenuate_hrtf_device(mic[pair], d_in, n, table[ch], facing, (0, 1, 0), ch, out.data_ptr())
+                    ctx.synchronize()
+                    crcs.append(_crc(out.cpu().numpy()))
+                ctx.ir_configure_hrtf(mic[pair], table, facing, (0, 1, 0), capi.IR_ALL, images)
+                got[exact] = (crcs, ctx.ir_download(True, 44100.0, capi.IR_EXACT), ctx.ir_download(True, 44100.0, capi.IR_FAST))
+            assert got[False][0] == got[True][0], "materialised hrtf kernel: a table row differs from the always-exact evaluation"
+            assert got[False][1].shape == got[True][1].shape and np.array_equal(got[False][1], got[True][1]) and got[True][1].any()
+            band_max = np.abs(got[True][1]).max(axis=2, keepdims=True)
+            assert (np.abs(got[False][2].astype(np.float64) - got[True][1]) <= 1e-5 * band_max).all()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v

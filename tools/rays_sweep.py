@@ -21,19 +21,27 @@ def main():
     counts = [int(x) for x in sys.argv[1:]] or [100000, 200000]
     nrefl = int(os.environ.get("SWEEP_REFLECTIONS", "128"))
     (scene, info) = scenes.cathedral(int(os.environ.get("SWEEP_TRIANGLES", "75000")))
-    ctx = capi.Context(0)
-    ctx.set_scene(scene)
+    group = int(os.environ.get("SWEEP_GROUP", "1"))      # > 1: that many contexts, n rays each, ONE path-kernel launch (rvb_trace_group)
+    ctxs = [capi.Context(0) for _ in range(group)]
+    for c in ctxs:
+        c.set_scene(scene)
+    ctx = ctxs[0]
     for n in counts:
-        ctx.set_directions(scenes.sphere_directions(n, seed=1))
+        for c in ctxs:
+            c.set_directions(scenes.sphere_directions(n, seed=1))
         times = {}
         for _ in range(4):
-            ctx.trace(info["mic"], info["source"], nrefl, dtypes.AIR_COEFFICIENTS)
-            ctx.synchronize()
+            if group > 1:
+                capi.Context.trace_group(ctxs, [info["mic"]] * group, [info["source"]] * group, nrefl, dtypes.AIR_COEFFICIENTS)
+            else:
+                ctx.trace(info["mic"], info["source"], nrefl, dtypes.AIR_COEFFICIENTS)
+            for c in ctxs:
+                c.synchronize()
             for k, v in ctx.last_timings():
                 times.setdefault(k, []).append(v)
         line = " ".join("%s %.3f" % (k, float(np.median(v[1:]))) for k, v in times.items())
         path = [float(np.median(v[1:])) for k, v in times.items() if k.startswith("path")][0]
-        print("lanes %s rays %d path/100k %.3f | %s" % (os.environ.get("RVB_PATH_LANES", "auto"), n, path * 1e5 / n, line), flush=True)
+        print("lanes %s rays %d x %d path/100k %.3f | %s" % (os.environ.get("RVB_PATH_LANES", "auto"), n, group, path * 1e5 / (n * group), line), flush=True)
 
 
 if __name__ == "__main__":
