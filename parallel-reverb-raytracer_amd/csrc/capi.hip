@@ -77,6 +77,7 @@ struct rvb_ctx {
     hipEvent_t pair_stage_free = nullptr;
     std::vector<rvb_impulse> pair_direct_host;
     std::vector<uint32_t> pair_range_host;
+    DevBuf image_items;                          // work list of the image-source check kernel
     DevBuf impulses, early, candidates, small, stamps, sort_keys, sort_scratch, sort_order, group_temp;       // small: [0] candidate count, [2..3] executed, [16..] direct, range
     // host mirror of `small`, fetched once per trace together with the first few image-source candidates (usually all of them).
     // One PINNED block: a device-to-host copy into pageable memory is staged by the runtime and blocks the host per call (three
@@ -168,6 +169,7 @@ const size_t kSmallExecuted = 8;
 const size_t kSmallRange = 16;      // two uint32
 const size_t kSmallMaxTime = 24;    // uint32
 const size_t kSmallTraceRange = 32; // two uint32: time range of the traced diffuse impulses (shadow_kernel)
+const size_t kSmallImageItems = 40; // uint32: entries of the image-source work list (image_plan_kernel)
 const size_t kSmallDirect = 64;     // rvb_impulse
 const size_t kSmallBytes = 128;
 const size_t kFirstCandidates = 32;
@@ -244,7 +246,7 @@ void rvb_destroy(rvb_ctx * ctx)
         return;
     (void) hipSetDevice(ctx->device);
     if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
-    for (DevBuf * b : {&ctx->nodes, &ctx->tris, &ctx->shade, &ctx->corners, &ctx->surfaces, &ctx->leafpos, &ctx->sort_keys, &ctx->sort_scratch, &ctx->sort_order, &ctx->group_temp, &ctx->directions_own, &ctx->impulses,
+    for (DevBuf * b : {&ctx->nodes, &ctx->tris, &ctx->shade, &ctx->corners, &ctx->surfaces, &ctx->leafpos, &ctx->sort_keys, &ctx->sort_scratch, &ctx->sort_order, &ctx->group_temp, &ctx->directions_own, &ctx->impulses, &ctx->image_items,
                        &ctx->early, &ctx->candidates, &ctx->small, &ctx->stamps, &ctx->images, &ctx->hrtf_table, &ctx->acc, &ctx->keys_a,
                        &ctx->keys_b, &ctx->vals_a, &ctx->vals_b, &ctx->sort_temp, &ctx->scratch_in, &ctx->scratch_out, &ctx->flat_in, &ctx->hist, &ctx->bin_starts, &ctx->own_sort_temp, &ctx->own_sort_keys, &ctx->own_sort_values,
                        &ctx->pair_geom, &ctx->pair_direct, &ctx->pair_range})
@@ -424,6 +426,7 @@ static int trace_prepare(rvb_ctx * ctx, const float * mics, const float * source
     RVB_HIP(ctx, ctx->impulses.ensure(imp_bytes));
     RVB_HIP(ctx, ctx->early.ensure(early_bytes));
     RVB_HIP(ctx, ctx->candidates.ensure((size_t) nrays * 9 * sizeof(rvb_image_candidate)));
+    RVB_HIP(ctx, ctx->image_items.ensure(((size_t) nrays * 9 + npairs) * 3 * sizeof(uint32_t)));      // (ray, bounce) entries, then a state word each
 
     // reference rayverb.cpp:600-616: outputs start zero-filled — path_kernel writes every slot of the
     // impulse array itself (work record or zeros), so no 819 MB fill is needed here
@@ -438,6 +441,9 @@ static int trace_prepare(rvb_ctx * ctx, const float * mics, const float * source
     a.early = ctx->early.as<uint32_t>();
     a.candidates = ctx->candidates.as<rvb_image_candidate>();
     a.candidate_count = reinterpret_cast<uint32_t *>(ctx->small.as<char>() + kSmallCandidateCount);
+    a.image_items = reinterpret_cast<ImageItem *>(ctx->image_items.p);
+    a.image_state = ctx->image_items.as<uint32_t>() + ((size_t) nrays * 9 + npairs) * 2;
+    a.image_item_count = reinterpret_cast<uint32_t *>(ctx->small.as<char>() + kSmallImageItems);
     a.direct = reinterpret_cast<rvb_impulse *>(ctx->small.as<char>() + kSmallDirect);
     a.npairs = (uint32_t) npairs;
     a.rays_per_pair = (uint32_t) ctx->nrays;

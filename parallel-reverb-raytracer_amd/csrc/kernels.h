@@ -20,6 +20,8 @@ struct SceneDev {                       // device pointers of the current scene
     unsigned long long * stamps = nullptr;   // diagnostic builds only (RVB_STAMPS)
 };
 
+// entry of the image-source work list: ray within the launch and bounce; index 0xFFFFFFFF = the direct path of pair `ray`
+struct ImageItem { uint32_t ray, index; };
 struct TraceArgs {
     SceneDev scene;
     const float4 * directions;          // [nrays]
@@ -27,6 +29,9 @@ struct TraceArgs {
     uint32_t * early;                   // [nrays * 9] triangle hit at bounce 0..8, 0xFFFFFFFF = none
     rvb_image_candidate * candidates;   // [nrays * 9] capacity
     uint32_t * candidate_count;
+    ImageItem * image_items;     // [nrays * 9 + npairs] (ray, bounce) pairs whose image ray crosses every image triangle (image_plan_kernel)
+    uint32_t * image_item_count;
+    uint32_t * image_state;             // [capacity of image_items] per listed pair: queries done (low half), queries failed (high half)
     rvb_impulse * direct;               // slot 0
     unsigned long long * executed;      // bounces executed
     uint32_t * sort_keys;               // [nrays * nreflections] leaf position of the triangle hit, 0xFFFFFFFF = no record (or null)
@@ -61,7 +66,7 @@ uint32_t rvb_path_lanes_for(uint64_t nrays, uint32_t concurrent);
 #define RVB_MAX_GROUP 4
 void rvb_launch_path_group(const TraceArgs * traces, uint32_t count, hipStream_t s);
 uint32_t rvb_shadow_lanes();        // lanes per record in the shadow kernel: 2 (shadow_pair_kernel) unless RVB_SHADOW_LANES=4
-// Phase C: one lane per (ray, bounce < 9): image-source validation (kernel.cpp:379-457) + slot 0.
+// Phase C: image-source validation (kernel.cpp:379-457) + slot 0: a plan kernel (one lane per ray) and a check kernel (four lanes per listed pair).
 void rvb_launch_images(const TraceArgs & a, hipStream_t s);
 // Phase B: one lane per (ray, bounce): diffuse shadow ray to the microphone and the final
 // Impulse (kernel.cpp:463-490).  Overwrites the work records.

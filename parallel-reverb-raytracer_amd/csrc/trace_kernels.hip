@@ -8,9 +8,11 @@
 //                  (a quarter fewer instructions per bounce; chosen when the rays in flight fill the chip
 //                  anyway, rvb_path_lanes_for).  Per bounce it leaves a 64-byte work record in the ray's
 //                  Impulse slot.
-//   image_kernel   one lane per ray: image-source validation of its first nine bounces (kernel.cpp:379-457),
-//                  the chain of mirrored triangles grown bounce by bounce.  Its inputs are only the triangles
-//                  the ray hit, so it runs beside the record grouping instead of inside the ray's loop.
+//   image_plan_kernel / image_check_kernel
+//                  image-source validation of a ray's first nine bounces (kernel.cpp:379-457): one lane per ray lists the
+//                  (ray, bounce) pairs whose image ray crosses every mirrored triangle, four lanes per listed pair and query
+//                  run the closest-hit / any-hit checks.  The inputs are only the triangles the ray hit, so this runs
+//                  beside the record grouping instead of inside the ray's loop.
 //   shadow_pair_kernel (shadow_kernel: the four-lane form, kept for measurements)
 //                  two lanes per (ray, bounce): the diffuse shadow ray to the microphone and the
 //                  final Impulse (kernel.cpp:463-490).  nrays*nreflections independent any-hit
@@ -713,76 +715,6 @@ __device__ __forceinline__ bool traverse_quad(const SceneDev & sc, const v3 o, c
     return job.hit;
 }
 
-// One-lane-per-query traversal (image_kernel): same tests, same rule, the lane walks all four
-// children itself.  stack: this lane's column, entries WAVE words apart.
-template <bool ANY>
-__device__ __forceinline__ bool traverse_lane(const SceneDev & sc, const v3 o, const v3 d, const float tmax,
-                                              uint32_t * __restrict__ stack, Hit & hit)
-{
-    const float ix = clamp_inv(d.x), iy = clamp_inv(d.y), iz = clamp_inv(d.z);
-    const float oix = o.x * ix, oiy = o.y * iy, oiz = o.z * iz;
-    const float neg_cull = -sc.cull_abs, cull_scale = 1.0f + sc.cull_rel;
-    float best_t = ANY ? tmax : __builtin_inff();
-    uint32_t best_i = NONE;
-    int sp = 0;
-    uint32_t ref = 0;
-    for (;;) {
-        while (!(ref & RVB_BVH_LEAF)) {
-            const uint4 * n = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(sc.nodes) + ref);
-            const float limit = fmaf(best_t, cull_scale, sc.cull_abs);
-            float key[4];
-            uint32_t cref[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const uint4 nc = n[c];
-                float tn;
-                const bool ok = slab(nc, ix, iy, iz, oix, oiy, oiz, limit, neg_cull, RVB_BVH_EMPTY, tn);
-                key[c] = ok ? tn : __builtin_inff();
-                cref[c] = ok ? nc.w : NONE;
-            }
-#define RVB_CSWAP(a, b) { if (key[b] < key[a]) { float tk = key[a]; key[a] = key[b]; key[b] = tk; uint32_t tr = cref[a]; cref[a] = cref[b]; cref[b] = tr; } }
-            if (!ANY) {
-                RVB_CSWAP(0, 1) RVB_CSWAP(2, 3) RVB_CSWAP(0, 2) RVB_CSWAP(1, 3) RVB_CSWAP(1, 2)
-            }
-#undef RVB_CSWAP
-            if (cref[3] != NONE) { stack[sp * WAVE] = cref[3]; ++sp; }
-            if (cref[2] != NONE) { stack[sp * WAVE] = cref[2]; ++sp; }
-            if (cref[1] != NONE) { stack[sp * WAVE] = cref[1]; ++sp; }
-            if (cref[0] != NONE) {
-                ref = cref[0];
-            } else if (sp > 0) {
-                --sp;
-                ref = stack[sp * WAVE];
-            } else {
-                ref = NONE;
-            }
-        }
-        if (ref == NONE)
-            break;
-        const uint32_t first = ref & 0x0FFFFFFFu;
-        const uint32_t count = ((ref >> 28) & 7u) + 1u;
-        for (uint32_t j = 0; j < count; ++j) {
-            const float4 * tp = reinterpret_cast<const float4 *>(sc.tris + first + j);
-            const float4 ta = tp[0], tb = tp[1], tc = tp[2];
-            const float dist = mt_intersect(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), o, d);
-            const uint32_t idx = __float_as_uint(tc.y);
-            if (ANY) {
-                if (dist > RVB_EPSILON && dist <= tmax)
-                    return true;
-            } else if (dist > RVB_EPSILON && (best_i == NONE || dist < best_t || (dist == best_t && idx < best_i))) {
-                best_t = dist;
-                best_i = idx;
-            }
-        }
-        if (sp > 0) { --sp; ref = stack[sp * WAVE]; } else break;
-    }
-    if (ANY)
-        return false;
-    hit.t = best_t;
-    hit.tri = best_i;
-    return best_i != NONE;
-}
-
 __device__ __forceinline__ v3 ld3(const float * p) { return mk3(p[0], p[1], p[2]); }
 
 // ------------------------------------------------------------------------------------------------
@@ -1101,15 +1033,6 @@ __device__ __forceinline__ TriVerts load_corners(const SceneDev & sc, uint32_t t
     return t;
 }
 
-// reference kernel.cpp:274-296 (point_intersection), one lane
-__device__ __forceinline__ bool point_visible_lane(const SceneDev & sc, v3 begin, v3 point, uint32_t * stack)
-{
-    const v3 b2p = point - begin;
-    const float mag = length3(b2p);
-    Hit h;
-    return !traverse_lane<true>(sc, begin, normalize3(b2p), mag, stack, h);
-}
-
 // A mirror plane of the image-source chain: the unit normal of a (mirrored) triangle and its first vertex.
 // mirror_point (rvb_math.h, kernel.cpp:216-221) recomputes that normal — a cross product, a square root and three divisions —
 // for every point it mirrors; here it is computed ONCE per plane with the same operations on the same operands, so the
@@ -1128,55 +1051,45 @@ __device__ __forceinline__ void mirror_point_on(v3 & p, const MirrorPlane & m)
     p = p + ((-m.n) * d) * 2.0f;
 }
 
-// One lane per RAY, walking its first nine bounces in order (as the reference's work-item does, kernel.cpp:379-457): the
-// mirrored triangle of bounce k is the hit triangle mirrored through the k planes before it, which are the same for every
-// later bounce of the ray — so the chain grows by one triangle per bounce instead of being rebuilt per (ray, bounce) pair
-// (45 triangle mirrorings per ray instead of 165, and a tenth of the mirror-plane normals).
-__global__ __launch_bounds__(WAVE) void image_kernel(TraceArgs a)
+// Image-source validation (kernel.cpp:379-457) in two kernels.
+//
+// A (ray, bounce) pair yields an image source iff (1) the ray from the source to the mirrored microphone crosses every mirrored
+// triangle of the chain (Möller–Trumbore on the image triangles: arithmetic only), (2) each segment of the un-mirrored path is the
+// closest hit of the real scene within +-EPSILON per component (a closest-hit query per segment), and (3) the last point sees the
+// microphone (an any-hit query).  Hardly any pair passes (1) — a few hundred of 900 000 at workload C2 — and round 2's kernel (one lane
+// per ray doing everything) took as long as its unluckiest LANE needed for up to eleven one-lane traversals in a row: 0.35 ms at 0.19
+// lane use.  Now:
+//   image_plan_kernel   one lane per ray walks its first nine bounces as before — the chain of mirrored triangles grown bounce by
+//                       bounce, one mirror plane per bounce — but only evaluates (1) and appends the pairs that pass to a list;
+//   image_check_kernel  FOUR lanes per listed pair and QUERY: rebuilds the pair's chain (all four lanes alike) and runs one of the
+//                       queries of (2) and (3) with the quad traversal of the path kernel (four children / triangles per step instead
+//                       of one); the pair's last query writes the image impulse.  The direct path (slot 0, one per source /
+//                       microphone pair) is one more list entry.
+// The operations on every value are the same as before, in the same order: results are bit-identical (tests/test_gpu_parity.py goldens).
+#define RVB_IMAGE_DIRECT 0xFFFFFFFFu
+
+// the ray's pair geometry (several (source, microphone) pairs may share a launch)
+__device__ __forceinline__ void image_pair_of(const TraceArgs & a, uint32_t ray, uint32_t & pair, v3 & mic, v3 & source)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t stack_lds[];   // [stack_entries][WAVE]
-    const uint32_t lane = threadIdx.x;
-    uint32_t * stack = stack_lds + lane;
-    const uint64_t ray = (uint64_t) blockIdx.x * WAVE + lane;
-    v3 mic = ld3(a.mic), source = ld3(a.source);
-    uint32_t pair = 0;
-    bool first_of_pair = ray == 0;
-    if (a.npairs > 1 && ray < a.nrays) {
-        pair = (uint32_t) ray / a.rays_per_pair;
-        first_of_pair = (uint32_t) ray == pair * a.rays_per_pair;
+    pair = 0;
+    mic = ld3(a.mic);
+    source = ld3(a.source);
+    if (a.npairs > 1) {
+        pair = ray / a.rays_per_pair;
         const float4 m4 = a.pair_mics[pair], s4 = a.pair_sources[pair];
         mic = mk3(m4.x, m4.y, m4.z);
         source = mk3(s4.x, s4.y, s4.z);
     }
+}
 
-    if (first_of_pair) {
-        // slot 0, the direct path (kernel.cpp:335-357): identical for every ray, computed once
-        rvb_impulse direct;
-        for (int b = 0; b < 8; ++b) direct.volume[b] = 0.0f;
-        for (int b = 0; b < 4; ++b) direct.position[b] = 0.0f;
-        direct.time = 0.0f;
-        direct.pad_[0] = direct.pad_[1] = direct.pad_[2] = 0.0f;
-        if (point_visible_lane(a.scene, source, mic, stack)) {
-            float one[8] = {1, 1, 1, 1, 1, 1, 1, 1};
-            make_image(a, mic, mic, source, one, direct);
-        }
-        a.direct[pair] = direct;
-    }
-    if (ray >= a.nrays)
-        return;
-
-    const uint32_t per_ray = RVB_NUM_IMAGE_SOURCE - 1;
-    const uint32_t * early = a.early + ray * per_ray;
-    const uint32_t last = a.nreflections < per_ray ? a.nreflections : per_ray;
+// One step of the chain (kernel.cpp:381-394): bounce `index`'s triangle through the planes so far, then the microphone through it.
+struct ImageChain {
     TriVerts prev[RVB_NUM_IMAGE_SOURCE - 1];
     MirrorPlane plane[RVB_NUM_IMAGE_SOURCE - 1];
-    v3 mic_reflection = mic;
-    for (uint32_t index = 0; index < last; ++index) {
-        const uint32_t tri_here = early[index];
-        if (tri_here == NONE)
-            break;                                // the ray escaped before this bounce
-        // kernel.cpp:381-394: this bounce's triangle through the planes so far, then the microphone through it
-        TriVerts current = load_corners(a.scene, tri_here);
+    v3 mic_reflection;
+    __device__ __forceinline__ void extend(const SceneDev & sc, uint32_t index, uint32_t tri_here)
+    {
+        TriVerts current = load_corners(sc, tri_here);
         for (uint32_t j = 0; j < index; ++j) {
             mirror_point_on(current.v0, plane[j]);
             mirror_point_on(current.v1, plane[j]);
@@ -1185,51 +1098,152 @@ __global__ __launch_bounds__(WAVE) void image_kernel(TraceArgs a)
         prev[index] = current;
         plane[index] = mirror_plane(current);
         mirror_point_on(mic_reflection, plane[index]);
+    }
+    // the k-th crossing of the image ray, un-mirrored (kernel.cpp:406-414); false: the image ray misses image triangle k
+    __device__ __forceinline__ bool crossing(uint32_t k, const v3 source, const v3 dir, v3 & ip) const
+    {
+        const float to_intersection = mt_intersect_verts(prev[k], source, dir);
+        if (to_intersection <= RVB_EPSILON)
+            return false;
+        ip = source + dir * to_intersection;
+        for (int l = (int) k - 1; l != -1; --l)
+            mirror_point_on(ip, plane[l]);
+        return true;
+    }
+};
 
-        // kernel.cpp:396-429
-        const v3 dir = normalize3(mic_reflection - source);
-        bool intersects = true;
-        v3 prev_intersection = source;
-        for (uint32_t k = 0; k != index + 1 && intersects; ++k) {
-            const float to_intersection = mt_intersect_verts(prev[k], source, dir);
-            if (to_intersection <= RVB_EPSILON) {
-                intersects = false;
-                break;
+__global__ __launch_bounds__(WAVE) void image_plan_kernel(TraceArgs a)
+{
+    const uint64_t ray = (uint64_t) blockIdx.x * WAVE + threadIdx.x;
+    if (a.npairs <= 1 && ray == 0) {              // slot 0, the direct path (defined even for an empty ray set)
+        const uint32_t at = atomicAdd(a.image_item_count, 1u);
+        a.image_items[at] = ImageItem{0u, RVB_IMAGE_DIRECT};
+    }
+    if (ray >= a.nrays)
+        return;
+    uint32_t pair;
+    v3 mic, source;
+    image_pair_of(a, (uint32_t) ray, pair, mic, source);
+    if (a.npairs > 1 && (uint32_t) ray == pair * a.rays_per_pair) {       // ... once per pair of a multi-pair launch
+        const uint32_t at = atomicAdd(a.image_item_count, 1u);
+        a.image_items[at] = ImageItem{pair, RVB_IMAGE_DIRECT};
+    }
+    const uint32_t per_ray = RVB_NUM_IMAGE_SOURCE - 1;
+    const uint32_t * early = a.early + ray * per_ray;
+    const uint32_t last = a.nreflections < per_ray ? a.nreflections : per_ray;
+    ImageChain chain;
+    chain.mic_reflection = mic;
+    for (uint32_t index = 0; index < last; ++index) {
+        const uint32_t tri_here = early[index];
+        if (tri_here == NONE)
+            break;                                // the ray escaped before this bounce
+        chain.extend(a.scene, index, tri_here);
+        const v3 dir = normalize3(chain.mic_reflection - source);      // kernel.cpp:396
+        bool crosses = true;
+        for (uint32_t k = 0; k != index + 1 && crosses; ++k) {
+            v3 ip;
+            crosses = chain.crossing(k, source, dir, ip);
+        }
+        if (crosses) {
+            const uint32_t at = atomicAdd(a.image_item_count, 1u);     // (at most nrays * 9 + npairs entries: the list's capacity)
+            a.image_items[at] = ImageItem{(uint32_t) ray, index};
+            a.image_state[at] = 0u;
+        }
+    }
+}
+
+// reference kernel.cpp:274-296 (point_intersection) by the quad's four lanes
+__device__ __forceinline__ bool point_visible_quad(const SceneDev & sc, v3 begin, v3 point, uint32_t * stack)
+{
+    const v3 b2p = point - begin;
+    const float mag = length3(b2p);
+    Hit h;
+    return !traverse_quad<true>(sc, begin, normalize3(b2p), mag, stack, h);
+}
+
+// Four lanes per (listed pair, query): a pair at bounce `index` owns index + 1 closest-hit queries and one any-hit query, which do not
+// depend on each other's results (the points come from the mirror chain, not from the queries), so they run side by side in
+// RVB_IMAGE_QUERIES quad slots per pair instead of one after the other (one quad walking a ninth-bounce pair's ten queries took as long
+// as round 2's whole kernel).  Every query adds its verdict to the pair's state word — low half: queries done, high half: queries
+// failed — and the one whose add completes the pair writes the image impulse if none failed.
+#define RVB_IMAGE_QUERIES (RVB_NUM_IMAGE_SOURCE + 1)
+__global__ __launch_bounds__(WAVE) void image_check_kernel(TraceArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t stack_lds[];   // [stack_entries][QUADS_PER_BLOCK]
+    const uint32_t q = threadIdx.x >> 2, c = threadIdx.x & 3u;
+    uint32_t * stack = stack_lds + q;
+    const uint64_t slots = (uint64_t) *a.image_item_count * RVB_IMAGE_QUERIES;
+    for (uint64_t slot = (uint64_t) blockIdx.x * QUADS_PER_BLOCK + q; slot < slots; slot += (uint64_t) gridDim.x * QUADS_PER_BLOCK) {
+        const uint32_t item = (uint32_t) (slot / RVB_IMAGE_QUERIES), k = (uint32_t) (slot % RVB_IMAGE_QUERIES);
+        const ImageItem it = a.image_items[item];
+        uint32_t pair;
+        v3 mic, source;
+        if (it.index == RVB_IMAGE_DIRECT) {
+            if (k != 0)
+                continue;
+            // slot 0 (kernel.cpp:335-357): identical for every ray of the pair, computed once
+            image_pair_of(a, it.ray * a.rays_per_pair, pair, mic, source);
+            rvb_impulse direct;
+            for (int b = 0; b < 8; ++b) direct.volume[b] = 0.0f;
+            for (int b = 0; b < 4; ++b) direct.position[b] = 0.0f;
+            direct.time = 0.0f;
+            direct.pad_[0] = direct.pad_[1] = direct.pad_[2] = 0.0f;
+            const bool visible = point_visible_quad(a.scene, source, mic, stack);
+            if (c == 0) {
+                if (visible) {
+                    float one[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+                    make_image(a, mic, mic, source, one, direct);
+                }
+                a.direct[it.ray] = direct;
             }
-            v3 ip = source + dir * to_intersection;
-            for (int l = (int) k - 1; l != -1; --l)
-                mirror_point_on(ip, plane[l]);
-
-            const v3 idir = normalize3(ip - prev_intersection);
+            continue;
+        }
+        if (k > it.index + 1)
+            continue;                             // this pair has fewer queries than slots
+        image_pair_of(a, it.ray, pair, mic, source);
+        const uint32_t * early = a.early + (uint64_t) it.ray * (RVB_NUM_IMAGE_SOURCE - 1);
+        ImageChain chain;
+        chain.mic_reflection = mic;
+        for (uint32_t index = 0; index <= it.index; ++index)
+            chain.extend(a.scene, index, early[index]);
+        // kernel.cpp:396-440: query k < index + 1 is the k-th segment of the un-mirrored path, query index + 1 the view of the microphone
+        const v3 dir = normalize3(chain.mic_reflection - source);
+        v3 begin = source, ip = source;
+        bool ok = true;
+        if (k > 0) ok = chain.crossing(k - 1, source, dir, begin);        // (cannot fail: image_plan_kernel evaluated the same expression)
+        if (k <= it.index) {
+            ok = ok && chain.crossing(k, source, dir, ip);
+            const v3 idir = normalize3(ip - begin);
             Hit h;
-            const bool found = traverse_lane<false>(a.scene, prev_intersection, idir, 0.0f, stack, h);
+            const bool found = traverse_quad<false>(a.scene, begin, idir, 0.0f, stack, h);
             const float hd = found ? h.t : 0.0f;                          // Intersection {0, 0, false}
-            const v3 nip = prev_intersection + idir * hd;
+            const v3 nip = begin + idir * hd;
             const bool lo = (nip.x - RVB_EPSILON < ip.x) && (nip.y - RVB_EPSILON < ip.y) && (nip.z - RVB_EPSILON < ip.z);
             const bool hi = (ip.x < nip.x + RVB_EPSILON) && (ip.y < nip.y + RVB_EPSILON) && (ip.z < nip.z + RVB_EPSILON);
-            intersects = found && lo && hi;
-            prev_intersection = ip;
+            ok = ok && found && lo && hi;
+        } else {
+            ok = point_visible_quad(a.scene, begin, mic, stack) && ok;    // kernel.cpp:431-440
         }
-        if (intersects)
-            intersects = point_visible_lane(a.scene, prev_intersection, mic, stack);   // kernel.cpp:431-440
-        if (!intersects)
+        if (c != 0)
             continue;
-
+        const uint32_t before = atomicAdd(a.image_state + item, ok ? 1u : 0x10001u);
+        if ((before & 0xFFFFu) + 1u != it.index + 2u || (before >> 16) != 0u || !ok)
+            continue;                             // not the pair's last query, or one of them failed
         // kernel.cpp:442-456: the ray's volume BEFORE this bounce's surface is applied
         float volume[8];
-        if (index == 0) {
+        if (it.index == 0) {
             for (int b = 0; b < 8; ++b) volume[b] = 1.0f;
         } else {
-            const float4 * rec = reinterpret_cast<const float4 *>(a.impulses + ray * a.nreflections + (index - 1));
+            const float4 * rec = reinterpret_cast<const float4 *>(a.impulses + (uint64_t) it.ray * a.nreflections + (it.index - 1));
             const float4 v0 = rec[0], v1 = rec[1];
             volume[0] = v0.x; volume[1] = v0.y; volume[2] = v0.z; volume[3] = v0.w;
             volume[4] = v1.x; volume[5] = v1.y; volume[6] = v1.z; volume[7] = v1.w;
         }
         rvb_image_candidate cand;
-        cand.ray = a.ray_offset + ray;
-        cand.slot = index + 1;
-        cand.index = tri_here + 1;
-        make_image(a, mic, mic_reflection, source, volume, cand.impulse);
+        cand.ray = a.ray_offset + it.ray;
+        cand.slot = it.index + 1;
+        cand.index = early[it.index] + 1;
+        make_image(a, mic, chain.mic_reflection, source, volume, cand.impulse);
         const uint32_t at = atomicAdd(a.candidate_count, 1u);
         a.candidates[at] = cand;
     }
@@ -1555,7 +1569,9 @@ void rvb_launch_path_group(const TraceArgs * traces, uint32_t count, hipStream_t
 void rvb_launch_images(const TraceArgs & a, hipStream_t s)
 {
     const unsigned blocks = (unsigned) ((a.nrays + WAVE - 1) / WAVE);     // one lane per ray
-    hipLaunchKernelGGL(image_kernel, dim3(blocks ? blocks : 1), dim3(WAVE), a.stack_entries * WAVE * sizeof(uint32_t), s, a);
+    hipLaunchKernelGGL(image_plan_kernel, dim3(blocks ? blocks : 1), dim3(WAVE), 0, s, a);
+    // a few hundred list entries at workload C2: 256 single-wave workgroups of 16 quads walk the list whatever its length
+    hipLaunchKernelGGL(image_check_kernel, dim3(256), dim3(WAVE), a.stack_entries * QUADS_PER_BLOCK * sizeof(uint32_t), s, a);
 }
 
 // Two lanes per record by default (shadow_pair_kernel): 12.8 M records fill the chip whatever the lane count, and a record costs
