@@ -41,7 +41,7 @@ from parallel_reverb_raytracer_amd import capi, distributed, dtypes, scenes  # n
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 # the guide's vector issue rate: v_fma_f32 (wave64) 2 cycles on each of 256 x 4 SIMDs at 2.4 GHz
 VALU_FMA_PEAK_GINST = 256 * 4 * 2.4 / 2
-PMC_FILE = "r02_pmc_n1.json"      # committed PMC passes of this command (tools/profile.sh): instruction mix, lane utilisation, HBM bytes
+PMC_FILE = "r03_pmc_n1.json"      # committed PMC passes of this command (tools/profile.sh): instruction mix, lane utilisation, HBM bytes
 BYTES_PER_BOUNCE = 69.75          # 64 B Impulse per bounce + (16 B direction + 10 x 72 B image slots) per ray at 128 bounces
 
 
@@ -423,15 +423,17 @@ def main():
         # per issued VALU instruction / 64 (SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU x 64)): masked-off lanes of the quad
         # kernels (a wave's 16 rays are not all in the step kind being executed) are issued but do nothing.
         valu = {}
-        for k in ("path_kernel", "path_pair_kernel", "shadow_kernel", "shadow_pair_kernel", "image_kernel"):
+        for k in ("path_kernel", "path_pair_kernel", "shadow_kernel", "shadow_pair_kernel"):
             v = pmc.get(k, {})
             if "SQ_INSTS_VALU" in v and solo.get(k):
                 a = v["SQ_INSTS_VALU"] / (solo[k] * 1e-3) / 1e9
+                # frac: against the guide's vector issue rate (every instruction priced as a v_fma_f32: 2 cycles per wave64 instruction per
+                # SIMD); frac_of_issue_model: against the time this kernel's own instruction mix needs at the issue costs measured per class
                 entry = {"bound": "valu_issue", "achieved": a, "unit": "G wave-instructions/s", "avg_launch_ms": solo[k],
                          "valu_instructions_per_launch": v["SQ_INSTS_VALU"], "numerators": from_profile,
-                         "frac_of_fma_peak": a / VALU_FMA_PEAK_GINST, "fma_peak": VALU_FMA_PEAK_GINST}
+                         "peak": VALU_FMA_PEAK_GINST, "frac": a / VALU_FMA_PEAK_GINST, "frac_of_fma_peak": a / VALU_FMA_PEAK_GINST}
                 if v.get("valu_issue_model_ms"):
-                    entry.update(peak=v["SQ_INSTS_VALU"] / (v["valu_issue_model_ms"] * 1e-3) / 1e9, frac=v["valu_issue_model_ms"] / solo[k],
+                    entry.update(frac_of_issue_model=v["valu_issue_model_ms"] / solo[k],
                                  issue_model_ms=v["valu_issue_model_ms"], instruction_mix=v.get("valu_mix"))
                 if v.get("valu_lane_utilisation") is not None:
                     entry["useful_lane_fraction"] = v["valu_lane_utilisation"]

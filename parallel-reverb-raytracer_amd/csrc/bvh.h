@@ -64,7 +64,7 @@ struct TriCorners { float v[9]; float pad[3]; };       // 48 B
 //      |dot(unit normal of T, direction)|  >  skip_a + skip_b * (length of the ray segment that ended on T)
 // skip_a, skip_b come from the error analysis in bvh_build.hip (assign_skips).  Without the skip every query first descends
 // into the wall it starts on (the padded boxes around its origin cannot be culled).
-struct TriShade { float n[3]; uint32_t surface; uint32_t skip_ref; float skip_a; float skip_b; uint32_t group; };     // 32 B
+struct TriShade { float n[3]; uint32_t surface; uint32_t skip_ref; float skip_a; float skip_b; uint32_t group; };     // 32 B; on the device `group` holds the triangle's leaf position (capi.hip)
 
 struct BuiltScene {
     std::vector<BvhNode> nodes;

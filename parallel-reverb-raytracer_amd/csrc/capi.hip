@@ -53,7 +53,7 @@ struct rvb_ctx {
 
     // scene
     bool have_scene = false;
-    DevBuf nodes, tris, shade, corners, surfaces, leafpos;
+    DevBuf nodes, tris, shade, corners, surfaces;
     SceneDev scene;
     uint64_t nnodes = 0, kept = 0;
     uint32_t depth = 0;
@@ -246,7 +246,7 @@ void rvb_destroy(rvb_ctx * ctx)
         return;
     (void) hipSetDevice(ctx->device);
     if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
-    for (DevBuf * b : {&ctx->nodes, &ctx->tris, &ctx->shade, &ctx->corners, &ctx->surfaces, &ctx->leafpos, &ctx->sort_keys, &ctx->sort_scratch, &ctx->sort_order, &ctx->group_temp, &ctx->directions_own, &ctx->impulses, &ctx->image_items,
+    for (DevBuf * b : {&ctx->nodes, &ctx->tris, &ctx->shade, &ctx->corners, &ctx->surfaces, &ctx->sort_keys, &ctx->sort_scratch, &ctx->sort_order, &ctx->group_temp, &ctx->directions_own, &ctx->impulses, &ctx->image_items,
                        &ctx->early, &ctx->candidates, &ctx->small, &ctx->stamps, &ctx->images, &ctx->hrtf_table, &ctx->acc, &ctx->keys_a,
                        &ctx->keys_b, &ctx->vals_a, &ctx->vals_b, &ctx->sort_temp, &ctx->scratch_in, &ctx->scratch_out, &ctx->flat_in, &ctx->hist, &ctx->bin_starts, &ctx->own_sort_temp, &ctx->own_sort_keys, &ctx->own_sort_values,
                        &ctx->pair_geom, &ctx->pair_direct, &ctx->pair_range})
@@ -325,16 +325,17 @@ int rvb_set_scene(rvb_ctx * ctx, const rvb_triangle * triangles, uint64_t ntrian
     };
     RVB_HIP(ctx, upload(ctx->nodes, built.nodes.data(), built.nodes.size() * sizeof(BvhNode)));
     RVB_HIP(ctx, upload(ctx->tris, built.tris.data(), built.tris.size() * sizeof(BvhTri)));
+    // the eighth word of a shading record (the builder's plane-group number, of no use on the device) carries the triangle's position
+    // in leaf order: the path kernel's record-grouping key comes with the 32 bytes it reads anyway instead of from a gather of its own
+    for (size_t i = 0; i < built.shade.size() && i < built.leafpos.size(); ++i) built.shade[i].group = built.leafpos[i];
     RVB_HIP(ctx, upload(ctx->shade, built.shade.data(), built.shade.size() * sizeof(TriShade)));
     RVB_HIP(ctx, upload(ctx->corners, built.corners.data(), built.corners.size() * sizeof(TriCorners)));
     RVB_HIP(ctx, upload(ctx->surfaces, surfaces, nsurfaces * sizeof(rvb_surface)));
-    RVB_HIP(ctx, upload(ctx->leafpos, built.leafpos.data(), built.leafpos.size() * sizeof(uint32_t)));
     ctx->scene.nodes = ctx->nodes.as<const BvhNode>();
     ctx->scene.tris = ctx->tris.as<const BvhTri>();
     ctx->scene.shade = ctx->shade.as<const TriShade>();
     ctx->scene.corners = ctx->corners.as<const TriCorners>();
     ctx->scene.surfaces = ctx->surfaces.as<const rvb_surface>();
-    ctx->scene.leafpos = ctx->leafpos.as<const uint32_t>();
     ctx->scene.ntris = (uint32_t) built.tris.size();
     // cull slack along the ray: the float distance of a triangle may differ from the exact one
     ctx->scene.cull_abs = built.pad;

@@ -13,7 +13,6 @@ struct SceneDev {                       // device pointers of the current scene
     const TriShade * shade = nullptr;
     const TriCorners * corners = nullptr;
     const rvb_surface * surfaces = nullptr;
-    const uint32_t * leafpos = nullptr;  // by original triangle index: position in tris[] (spatial order)
     uint32_t ntris = 0;                  // entries of tris[]
     float cull_abs = 0.0f;              // slack added to the running closest distance when culling
     float cull_rel = 0.0f;

@@ -45,6 +45,16 @@
 #define RVB_LDS_NODES 0        // experiment: top nodes of the BVH staged in LDS per workgroup (path_kernel); 21 = levels 0-2
 #endif
 
+// tools/isa_mix.py: -DRVB_ISA_MARKS=1 leaves comment lines in the ISA at the borders of the step kinds of the vote loops (never in the shipped build)
+#ifndef RVB_ISA_MARKS
+#define RVB_ISA_MARKS 0
+#endif
+#if RVB_ISA_MARKS
+#define RVB_MARK(name) asm volatile("; RVB_MARK " name)
+#else
+#define RVB_MARK(name)
+#endif
+
 #define WAVE 64
 #define QUADS_PER_BLOCK 16          // rays (or records) per 64-lane workgroup in the quad kernels
 #define NONE 0xFFFFFFFFu
@@ -541,6 +551,7 @@ __device__ __forceinline__ void traverse_pairs_vote(const SceneDev & sc, uint32_
     }
     if (job.next(o, d, tmax)) RVB_RESET_QUERY()
     for (;;) {
+        RVB_MARK("vote");
         const unsigned long long m_node = __builtin_amdgcn_ballot_w64((int32_t) ref >= 0);
         const unsigned long long m_done = __builtin_amdgcn_ballot_w64(ref == NONE);
         const unsigned long long m_leaf = __builtin_amdgcn_ballot_w64((int32_t) ref < (int32_t) IDLE);
@@ -548,6 +559,7 @@ __device__ __forceinline__ void traverse_pairs_vote(const SceneDev & sc, uint32_
         if ((n_node | n_done | n_leaf) == 0)
             break;
         if (n_node >= n_leaf && n_node >= n_done) {
+            RVB_MARK("node");
             if ((int32_t) ref >= 0) {
 #if RVB_LDS_NODES
                 uint4 n0, n1;
@@ -589,6 +601,7 @@ __device__ __forceinline__ void traverse_pairs_vote(const SceneDev & sc, uint32_
                 }
             }
         } else if (n_leaf >= n_done) {
+            RVB_MARK("leaf");
             if ((int32_t) ref < (int32_t) IDLE) {
                 // triangles h and h + 2 of the leaf (a two-triangle leaf gives each lane one)
                 const uint32_t first = ref & 0x0FFFFFFFu;
@@ -610,6 +623,7 @@ __device__ __forceinline__ void traverse_pairs_vote(const SceneDev & sc, uint32_
                 if (sp > 0) { --sp; ref = stack[sp * PAIRS_PER_BLOCK]; } else ref = NONE;
             }
         } else {
+            RVB_MARK("done");
             if (ref == NONE) {
                 Hit hit;
                 hit.t = __uint_as_float((uint32_t) (best_key >> 32));
@@ -619,6 +633,7 @@ __device__ __forceinline__ void traverse_pairs_vote(const SceneDev & sc, uint32_
                 if (job.next(o, d, tmax)) RVB_RESET_QUERY()
             }
         }
+        RVB_MARK("loop_end");
     }
 #undef RVB_RESET_QUERY
 }
@@ -843,7 +858,7 @@ struct PathJob {
         if (c == 0 && index < RVB_NUM_IMAGE_SOURCE - 1)
             a.early[ray * (RVB_NUM_IMAGE_SOURCE - 1) + index] = h.tri;
         if (c == 1 && a.sort_keys)
-            a.sort_keys[record] = a.scene.leafpos[h.tri];
+            a.sort_keys[record] = __float_as_uint(sk.w);               // the triangle's position in leaf order (rvb_set_scene put it there)
 #if RVB_PROBE_NO_STORES
         }
 #endif

@@ -10,7 +10,8 @@ import sys
 
 tag = sys.argv[1]
 out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
-SHORT = ["path_kernel", "path_pair_group_kernel", "path_pair_kernel", "image_kernel", "shadow_kernel", "shadow_pair_kernel", "histogram_fast_kernel", "histogram_transpose_kernel", "attenuate_kernel",
+SHORT = ["path_kernel", "path_pair_group_kernel", "path_pair_kernel", "image_plan_kernel", "image_check_kernel", "shadow_kernel", "shadow_pair_kernel",
+         "bin_keys_hrtf_kernel", "ordered_sum_hrtf_kernel", "histogram_fast_kernel", "histogram_transpose_kernel", "attenuate_kernel",
          "time_range_kernel", "bin_keys_kernel", "ordered_sum_kernel", "radix_sort_onesweep_iteration", "radix_sort_onesweep_global_offsets"]
 
 # VALU issue model: dynamic instruction mix (per-class PMC counters) x measured issue cost per class (tools/inst_probe.hip at
