@@ -63,6 +63,8 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     p.add_argument("--rehearse-collectives", action="store_true",
                    help="with one rank: create the process group anyway and run every collective of the multi-GPU path on it")
+    p.add_argument("--exact-chain", action="store_true", help="several ranks, exact mode: the ranks continue ONE serial sum in ray order (bit-identical "
+                   "to one GPU; their binning stages run one after the other) instead of all-reducing their own serial sums")
     p.add_argument("--no-host-copy", action="store_true", help="leave the finished histograms in HBM (the round-1/2 metric; diagnostic)")
     p.add_argument("--master-port", type=int, default=0, help="rendezvous port when bench.py starts its own ranks (0: a free one)")
     p.add_argument("--contexts", type=int, default=4, help="contexts per GPU that take turns (4: the traces of IRs i+2, i+3 are enqueued "
@@ -227,7 +229,7 @@ def main():
                 for k, v in tracer.last_timings():
                     sink.setdefault(k, []).append(v)
         return dict(speakers_dir=speakers_dir, speakers_coeff=speakers_coeff, sample_rate=sr, trim_predelay=True,
-                    mode=mode if ir_mode is None else ir_mode, host_out=host_out if to_host else None,
+                    mode=mode if ir_mode is None else ir_mode, host_out=host_out if to_host else None, chain_exact=args.exact_chain,
                     rank=rank, world=world, ray_offset=first_ray, device=device, on_stage=on_stage, collectives=grouped)
 
     # an impulse response is generated once [channels][8][nbins] is ON THE HOST.  Every histogram is copied to
@@ -332,12 +334,15 @@ def main():
     bit_equal = bool(torch.equal(timed_hist, solo_host))
     band_max = solo_host.double().abs().amax(dim=2, keepdim=True).clamp_min(1e-300)
     worst = float(((timed_hist.double() - solo_host.double()).abs() / band_max).max()) if timed_hist.shape == solo_host.shape else float("inf")
-    must_be_equal = args.mode == "exact" and world == 1
+    must_be_equal = args.mode == "exact" and (world == 1 or args.exact_chain)
     timed_check = {"last_timed_histogram_equals_solo_ir": bit_equal, "max_abs_err_over_band_max": worst,
                    "required": "bit-equal" if must_be_equal else "<= 1e-5 of each band's maximum"}
     if (must_be_equal and not bit_equal) or worst > 1e-5 or not bool(solo_host.any()):
         print("bench.py: the timed region's histogram differs from a solo IR: %s" % json.dumps(timed_check), file=sys.stderr)
         sys.exit(4)
+    if rank == 0 and os.environ.get("RVB_BENCH_CRC"):       # (checks of the multi-rank modes against one context tracing all the rays)
+        import zlib
+        print("bench.py: histogram nbins %d crc32 %d" % (solo_host.shape[2], zlib.crc32(solo_host.numpy().tobytes())), file=sys.stderr)
     del solo_hist, solo_host, timed_hist
 
     # the other binning mode through the same timed pipeline, and how far the float-atomic histogram is from the exact one
@@ -479,7 +484,7 @@ def main():
                                    % (scene[0].shape[0], rays_per_gpu, nrefl, sr, args.mode,
                                       "" if world == 1 else " (BASELINE configs[2]'s shape: %d rays over %d GPUs)" % (rays_per_gpu * world, world)),
                        "triangles": int(scene[0].shape[0]), "rays_per_gpu": rays_per_gpu, "reflections": nrefl,
-                       "histogram_mode": args.mode + ((": the reference's serial float sum over all impulses, bit for bit" if world == 1 else
+                       "histogram_mode": args.mode + ((": the reference's serial float sum over all impulses, bit for bit" if world == 1 or args.exact_chain else
                                                        ": every rank's histogram is the serial float sum over ITS impulses; the ranks' histograms are then "
                                                        "added by one all-reduce, so the result is within 1e-5 of each band's maximum of the single-GPU "
                                                        "serial sum, not bit-equal to it (the bit-equal chain over devices is rvb_multi_*, csrc/multi.hip)")

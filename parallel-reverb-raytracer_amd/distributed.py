@@ -107,7 +107,7 @@ def begin_ir(tracer, mic, source, nreflections, air, ray_offset=0):
 def generate_ir(tracer, mic, source, nreflections, air, speakers_dir=None, speakers_coeff=None, sample_rate=44100.0,
                 trim_predelay=True, mode=capi.IR_FAST, rank=0, world=1, ray_offset=0, device="cpu",
                 which=capi.IR_ALL, remove_direct=False, on_stage=None, begun=False, model=None, collectives=None, defer=False,
-                host_out=None):
+                host_out=None, chain_exact=False):
     """One impulse response from the rays already set on `tracer`.  Returns (hist tensor
     [nchannels][8][nbins] — identical on every rank —, info dict).
 
@@ -120,6 +120,12 @@ def generate_ir(tracer, mic, source, nreflections, air, speakers_dir=None, speak
     begun=True: begin_ir(tracer, ...) has already enqueued this IR's trace.  A caller with two contexts per GPU
     calls begin_ir on the second before generate_ir(..., begun=True) on the first, so that one IR's trace (VALU-bound)
     runs beside the other's record grouping, binning, host work and collectives (IrPipeline below).
+
+    chain_exact=True (several ranks, exact mode): instead of all-reducing the ranks' serial sums — which is the single-GPU histogram
+    only up to float re-association — the ranks continue ONE serial sum in ray order: rank r receives the histogram from rank r-1,
+    folds its own diffuse impulses on top (rvb_ir_accumulate in exact mode adds to what the histogram holds), hands it to rank r+1;
+    the last rank adds the merged image sources (the reference's order: diffuse, then images — rayverb.cpp:708-714) and broadcasts.
+    Bit-identical to one GPU and to flattenImpulses; the binning stages of the ranks run one after the other (the traces do not).
 
     host_out(shape) -> pinned host tensor: the finished histogram is also copied there (info["host"]) — enqueued behind the binning
     (behind the all-reduce with collectives) on the tracer's export stream, so neither the host nor the tracer's next trace waits for
@@ -166,16 +172,19 @@ def generate_ir(tracer, mic, source, nreflections, air, speakers_dir=None, speak
             model.configure(tracer, mic, capi.IR_IMAGES, images)
             ranges.append(tracer.ir_time_range())
         lo, hi = combine_time_ranges(ranges)
-        mine = which if rank == 0 else (which & capi.IR_DIFFUSE)
+        chain = bool(chain_exact) and mode == capi.IR_EXACT and world > 1
+        adds_images = rank == (world - 1 if chain else 0)      # one rank adds the merged image impulses: the last of a chain, else rank 0
+        mine = which if adds_images else (which & capi.IR_DIFFUSE)
         contributes = mine != 0
-        if contributes:
-            model.configure(tracer, mic, mine, images if rank == 0 else empty)
-        if rank != 0:
+        if contributes and not chain:
+            model.configure(tracer, mic, mine, images if adds_images else empty)
+        if not adds_images and not chain:
             images = empty
     predelay = lo if trim_predelay else 0.0
     nbins = tracer.ir_bins(hi, predelay, sample_rate)
     hist = torch.zeros((model.nchannels, 8, nbins), device=device, dtype=torch.float32)
-    if contributes:                                      # (the tracer's stream waits for torch's zero fill by an event)
+    chain = collectives and bool(chain_exact) and mode == capi.IR_EXACT and world > 1
+    if contributes and not chain:                        # (the tracer's stream waits for torch's zero fill by an event)
         tracer.ir_accumulate_tensor(predelay, sample_rate, nbins, mode, hist)
     info = {"nbins": nbins, "predelay": predelay, "images": int(images.shape[0]), "max_time": hi}
     host = host_out(tuple(hist.shape)) if host_out is not None else None
@@ -189,12 +198,28 @@ def generate_ir(tracer, mic, source, nreflections, air, speakers_dir=None, speak
     def finish():
         if on_stage:
             on_stage("accumulate", tracer)
-        tracer.synchronize()
-        if collectives:
-            dist.all_reduce(hist, op=dist.ReduceOp.SUM)  # RCCL over xGMI: [channels][8][nbins] floats
+        if chain:
+            # one serial sum over all ranks, in ray order (see the docstring)
+            if rank > 0:
+                dist.recv(hist, src=rank - 1)
+            if which & capi.IR_DIFFUSE:
+                model.configure(tracer, mic, capi.IR_DIFFUSE, empty)
+                tracer.ir_accumulate_tensor(predelay, sample_rate, nbins, mode, hist)
+                tracer.synchronize()
+            if rank == world - 1 and (which & capi.IR_IMAGES) and images.shape[0]:
+                model.configure(tracer, mic, capi.IR_IMAGES, images)
+                tracer.ir_accumulate_tensor(predelay, sample_rate, nbins, mode, hist)
+                tracer.synchronize()
+            if rank < world - 1:
+                dist.send(hist, dst=rank + 1)
+            dist.broadcast(hist, src=world - 1)
+        else:
+            tracer.synchronize()
+            if collectives:
+                dist.all_reduce(hist, op=dist.ReduceOp.SUM)  # RCCL over xGMI: [channels][8][nbins] floats
         if host is not None and (collectives or not hasattr(tracer, "export_tensor_to_host")):
             if hist.is_cuda and hasattr(tracer, "export_tensor_to_host"):
-                tracer.ir_accumulate_wait_for_torch()    # the all-reduce ran on torch's stream: the tracer's stream waits for it by an event
+                tracer.ir_accumulate_wait_for_torch()    # the collective ran on torch's stream: the tracer's stream waits for it by an event
                 tracer.export_tensor_to_host(hist, host)
             else:
                 host.copy_(hist)

@@ -60,11 +60,18 @@ class OracleTracer:
         return int(np.round(np.float32(t * np.float32(sample_rate))) + 1)
 
     def ir_accumulate_tensor(self, predelay, sample_rate, nbins, mode, tensor):
+        """Continues the reference's serial float sum (rayverb.cpp:67-74) ON TOP of what the histogram holds, impulse by impulse, as
+        rvb_ir_accumulate does in exact mode (on a zeroed histogram that is flattenImpulses itself)."""
         for ch, att in enumerate(self.channels):
             att = att.copy()
             self.oracle.fix_predelay(att, predelay)
-            flat = self.oracle.flatten(att, sample_rate)
-            tensor[ch, :, :flat.shape[1]] += __import__("torch").from_numpy(flat)
+            hist = tensor[ch].numpy()                                  # shares the tensor's memory
+            x = att["time"] * np.float32(sample_rate)                  # rayverb.cpp:69 round(): half away from zero (x >= 0; x - floor(x) is exact)
+            f = np.floor(x)
+            bins = np.where(x - f >= np.float32(0.5), f + 1, f).astype(np.int64)
+            vol = att["volume"]
+            for i in range(att.shape[0]):
+                hist[:, bins[i]] += vol[i]
 
     def synchronize(self):
         pass

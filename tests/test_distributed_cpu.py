@@ -19,7 +19,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, out_dir, total_rays, nrefl, capacity=None):
+def _worker(rank, world, port, out_dir, total_rays, nrefl, capacity=None, chain=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -47,9 +47,10 @@ def _worker(rank, world, port, out_dir, total_rays, nrefl, capacity=None):
 
     hist, meta = distributed.generate_ir(tracer, info["mic"], info["source"], nrefl, dtypes.AIR_COEFFICIENTS,
                                          [(-1, 0, -1), (1, 0, -1)], [0.5, 0.5], 44100.0, trim_predelay=True,
-                                         mode=capi.IR_EXACT, rank=rank, world=world, ray_offset=first, device="cpu", host_out=host_out)
+                                         mode=capi.IR_EXACT, rank=rank, world=world, ray_offset=first, device="cpu", host_out=host_out,
+                                         chain_exact=chain)
     assert len(landed) == 1 and meta["host"] is landed[0] and torch.equal(landed[0], hist)     # the host copy is the REDUCED histogram
-    np.savez(os.path.join(out_dir, "rank%d_of%d%s.npz" % (rank, world, "" if capacity is None else "_cap%d" % capacity)), hist=hist.numpy(), nbins=meta["nbins"],
+    np.savez(os.path.join(out_dir, "rank%d_of%d%s%s.npz" % (rank, world, "" if capacity is None else "_cap%d" % capacity, "_chain" if chain else "")), hist=hist.numpy(), nbins=meta["nbins"],
              predelay=meta["predelay"], images=meta["images"])
     if world > 1:
         dist.barrier()
@@ -82,6 +83,19 @@ def test_two_rank_gloo_equals_single_process(tmp_path, oracle):
     scale = np.abs(a).max(axis=2, keepdims=True) + 1e-30
     assert (np.abs(a - b) <= 1e-5 * scale).all()
     assert np.abs(a).sum() > 0
+
+
+def test_two_rank_chained_exact_mode_is_bit_identical_to_a_single_process(tmp_path, oracle):
+    """chain_exact: the ranks continue ONE serial float sum in ray order (rank 0's impulses, then rank 1's on top, the merged image
+    sources last) instead of all-reducing their own sums: the result must be the single-process histogram bit for bit, on both ranks."""
+    import torch.multiprocessing as mp
+    total_rays, nrefl = 96, 10
+    _worker(0, 1, 0, str(tmp_path), total_rays, nrefl)
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), total_rays, nrefl, None, True), nprocs=2, join=True)
+    one = np.load(os.path.join(str(tmp_path), "rank0_of1.npz"))
+    two = [np.load(os.path.join(str(tmp_path), "rank%d_of2_chain.npz" % r)) for r in (0, 1)]
+    assert np.array_equal(two[0]["hist"], one["hist"]) and np.array_equal(two[1]["hist"], one["hist"]) and one["hist"].any()
+    assert int(two[0]["nbins"]) == int(one["nbins"]) and int(two[1]["images"]) == int(one["images"])
 
 
 def test_candidate_exchange_overflow_round(tmp_path, oracle):

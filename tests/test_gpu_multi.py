@@ -87,3 +87,41 @@ def test_rccl_all_reduce_is_bound_and_runs(case, single):
         assert np.array_equal(m.ir_speakers(mic, SPEAKERS[0], SPEAKERS[1], True, 44100.0, capi.IR_EXACT), exact)
     finally:
         m.close()
+
+
+def test_two_processes_chained_exact_mode_equals_one_context(tmp_path):
+    """One process per rank (bench.py --gpus 2 starts its own two ranks; gloo, both on the test box's one GPU): with --exact-chain
+    the ranks continue ONE serial sum in ray order, so the [2][8][nbins] histogram of 2 x 3000 rays must have the bytes of ONE
+    context tracing the same 6000 rays; with the default all-reduce of per-rank sums it is within the stated tolerance."""
+    import os
+    import re
+    import subprocess
+    import sys
+    import zlib
+    import torch
+    from conftest import ROOT
+    from parallel_reverb_raytracer_amd import capi, distributed
+    args = ["--gpus", "2", "--backend", "gloo", "--share-gpu", "--rays", "3000", "--reflections", "24", "--triangles", "6000",
+            "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-extras"]
+    env = dict(os.environ, RVB_BENCH_CRC="1")
+    found = {}
+    for label, extra in (("chain", ["--exact-chain"]), ("allreduce", [])):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args + extra, capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = __import__("json").loads(r.stdout.strip().splitlines()[-1])
+        assert line["n_gpus"] == 2
+        m = re.search(r"histogram nbins (\d+) crc32 (\d+)", r.stderr)
+        assert m, r.stderr[-2000:]
+        found[label] = (int(m.group(1)), int(m.group(2)), line["timed_region_check"])
+    scene, info = scenes.cathedral(6000)
+    ctx = capi.Context(0)
+    try:
+        ctx.set_scene(scene)
+        ctx.set_directions(scenes.sphere_directions(6000, seed=1))
+        hist, meta = distributed.generate_ir(ctx, info["mic"], info["source"], 24, AIR_COEFFICIENTS, SPEAKERS[0], SPEAKERS[1], 44100.0,
+                                             trim_predelay=True, mode=capi.IR_EXACT, device=torch.device("cuda", 0))
+        want = (int(meta["nbins"]), zlib.crc32(hist.cpu().numpy().tobytes()))
+    finally:
+        ctx.close()
+    assert found["chain"][:2] == want and found["chain"][2]["required"] == "bit-equal"
+    assert found["allreduce"][0] == want[0] and found["allreduce"][2]["max_abs_err_over_band_max"] <= 1e-5
