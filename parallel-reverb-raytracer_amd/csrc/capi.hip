@@ -485,7 +485,7 @@ static int trace_prepare(rvb_ctx * ctx, const float * mics, const float * source
     // record bucketing for coherent shadow rays (RVB_SHADOW_SORT=0 turns it off)
     static const bool sort_records = !(getenv("RVB_SHADOW_SORT") && getenv("RVB_SHADOW_SORT")[0] == '0');
     const uint64_t nrecords = nrays * nreflections;
-    a.sort_keys = nullptr; a.sort_order = nullptr;
+    a.sort_keys = nullptr; a.sort_keys16 = nullptr; a.key_shift = 0; a.sort_order = nullptr;
     int key_bits = 1;
     while (key_bits < 32 && (1ull << key_bits) < ctx->scene.ntris) ++key_bits;
     // The grouping only has to bring neighbouring triangles together: the top 16 bits of the leaf position are two
@@ -499,7 +499,15 @@ static int trace_prepare(rvb_ctx * ctx, const float * mics, const float * source
         RVB_HIP(ctx, ctx->group_temp.ensure(group_bytes));
         // slots of escaped rays get key 0xFFFFFFFF from path_kernel: they land in the last bucket and the
         // shadow kernel skips them by their valid flag
-        a.sort_keys = ctx->sort_keys.as<uint32_t>();
+        // 16-bit keys in 64-byte runs (trace_kernels.hip, flush_key_run) whenever a ray's row divides into whole runs and rocPRIM sorts;
+        // 32-bit keys, one store per record, otherwise (and for RVB_SORT=own, RVB_KEY_RUNS=0)
+        static const bool runs_off = getenv("RVB_KEY_RUNS") && getenv("RVB_KEY_RUNS")[0] == '0';
+        if (nreflections % 32 == 0 && !own_sort_enabled() && !runs_off) {
+            a.sort_keys16 = ctx->sort_keys.as<uint16_t>();
+            a.key_shift = (uint32_t) std::max(0, key_bits - 16);
+        } else {
+            a.sort_keys = ctx->sort_keys.as<uint32_t>();
+        }
     }
     a.nrays = nrays;
     a.nreflections = (uint32_t) nreflections;
@@ -521,7 +529,7 @@ static int trace_prepare(rvb_ctx * ctx, const float * mics, const float * source
     static const bool probe_zero = getenv("RVB_PROBE_ZERO_RECORDS") != nullptr;
     if (probe_zero) {
         RVB_HIP(ctx, hipMemsetAsync(ctx->impulses.p, 0, imp_bytes, ctx->stream));
-        if (a.sort_keys) RVB_HIP(ctx, hipMemsetAsync(ctx->sort_keys.p, 0xFF, nrecords * 4, ctx->stream));
+        if (a.sort_keys || a.sort_keys16) RVB_HIP(ctx, hipMemsetAsync(ctx->sort_keys.p, 0xFF, nrecords * (a.sort_keys ? 4 : 2), ctx->stream));
     }
 
     ctx->reset_timings();
@@ -549,14 +557,20 @@ static int trace_finish(rvb_ctx * ctx, TracePlan & plan, const float * mics)
     ctx->end_timing(ctx->side_stream);
     RVB_HIP(ctx, hipEventRecord(ctx->side_done, ctx->side_stream));
     a.scene.stamps = ctx->stamps.as<unsigned long long>() + 16;
-    if (a.sort_keys) {
+    if (a.sort_keys || a.sort_keys16) {
         ctx->begin_timing("record_sort_kernels");
         a.sort_order = ctx->sort_order.as<uint32_t>();
         RVB_HIP(ctx, hipGetLastError());
         // one grouping per pair (a pair's shadow rays share a microphone; records are [pair][ray][bounce])
         const uint64_t per_pair = ctx->nrays * nreflections;
         for (uint64_t p = 0; p < npairs; ++p) {
-            if (own_sort_enabled()) {
+            if (a.sort_keys16) {
+                // key16 = leaf position >> key_shift: its top group_bits bits are bits [end - group_bits, end) with end = min(16, key_bits)
+                const int end = std::min(16, key_bits);
+                RVB_HIP(ctx, rvb_group_records16(ctx->group_temp.p, ctx->group_temp.cap, a.sort_keys16 + p * per_pair,
+                                                 ctx->sort_scratch.as<uint16_t>() + p * per_pair, a.sort_order + p * per_pair, per_pair,
+                                                 (uint32_t) (p * per_pair), std::max(0, end - group_bits), end, ctx->stream));
+            } else if (own_sort_enabled()) {
                 const int rc = own_sort(ctx, a.sort_keys + p * per_pair, (uint32_t) (p * per_pair), per_pair, std::max(0, key_bits - group_bits), key_bits,
                                         ctx->sort_scratch.as<uint32_t>() + p * per_pair, a.sort_order + p * per_pair, false);
                 if (rc != RVB_OK) return rc;

@@ -34,6 +34,9 @@ struct TraceArgs {
     rvb_impulse * direct;               // slot 0
     unsigned long long * executed;      // bounces executed
     uint32_t * sort_keys;               // [nrays * nreflections] leaf position of the triangle hit, 0xFFFFFFFF = no record (or null)
+    uint16_t * sort_keys16;             // the same as 16-bit keys (leaf position >> key_shift, 0xFFFF = no record), written in 64-byte runs through LDS
+                                        // (path kernels; needs nreflections % 32 == 0); exactly one of sort_keys / sort_keys16 is set, or neither
+    uint32_t key_shift;
     uint32_t * sort_order;              // [nrays * nreflections] record indices grouped by bucket
     uint32_t * time_range;              // [2] float bits: min non-zero / max time of non-zero diffuse impulses
     uint64_t nrays;
@@ -75,6 +78,8 @@ void rvb_launch_shadow(const TraceArgs & a, hipStream_t s);
 size_t rvb_group_records_temp_bytes(uint64_t n);
 hipError_t rvb_group_records(void * temp, size_t temp_bytes, const uint32_t * keys, uint32_t * keys_scratch, uint32_t * order,
                              uint64_t n, uint32_t first_record, int begin_bit, int end_bit, hipStream_t s);
+hipError_t rvb_group_records16(void * temp, size_t temp_bytes, const uint16_t * keys, uint16_t * keys_scratch, uint32_t * order,
+                               uint64_t n, uint32_t first_record, int begin_bit, int end_bit, hipStream_t s);
 
 // ---- streaming kernels (stream_kernels.hip) ---------------------------------------------------
 struct AttenuationModel {

@@ -805,12 +805,15 @@ void rvb_sort_pairs(void * temp, size_t temp_bytes, const uint32_t * keys_in, ui
 // key bits [begin_bit, end_bit) only — a one- or two-pass radix sort; values come from a counting iterator.
 size_t rvb_group_records_temp_bytes(uint64_t n)
 {
+    size_t bytes16 = 0;
+    (void) rocprim::radix_sort_pairs(nullptr, bytes16, (const uint16_t *) nullptr, (uint16_t *) nullptr,
+                                     rocprim::counting_iterator<uint32_t>(0), (uint32_t *) nullptr, (size_t) n, 0, 16, (hipStream_t) 0);
     size_t bytes = 0;
     const hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t *) nullptr, (uint32_t *) nullptr,
                                                    rocprim::counting_iterator<uint32_t>(0), (uint32_t *) nullptr, (size_t) n, 0, 32,
                                                    (hipStream_t) 0);
     (void) hipGetLastError();          // a size query launches nothing; drop whatever state it left behind
-    return e == hipSuccess ? bytes : 0;
+    return e == hipSuccess ? std::max(bytes, bytes16) : 0;
 }
 
 hipError_t rvb_group_records(void * temp, size_t temp_bytes, const uint32_t * keys, uint32_t * keys_scratch, uint32_t * order,
@@ -818,6 +821,14 @@ hipError_t rvb_group_records(void * temp, size_t temp_bytes, const uint32_t * ke
 {
     if (n == 0) return hipSuccess;
     // values = record numbers first_record .. first_record + n (a slice of the launch's records)
+    return rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_scratch, rocprim::counting_iterator<uint32_t>(first_record), order,
+                                     (size_t) n, (unsigned) begin_bit, (unsigned) end_bit, s);
+}
+
+hipError_t rvb_group_records16(void * temp, size_t temp_bytes, const uint16_t * keys, uint16_t * keys_scratch, uint32_t * order,
+                               uint64_t n, uint32_t first_record, int begin_bit, int end_bit, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
     return rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_scratch, rocprim::counting_iterator<uint32_t>(first_record), order,
                                      (size_t) n, (unsigned) begin_bit, (unsigned) end_bit, s);
 }

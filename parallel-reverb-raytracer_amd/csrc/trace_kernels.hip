@@ -774,6 +774,7 @@ __device__ __forceinline__ lds_float4_ptr stage_surfaces(const TraceArgs & a, ui
 #ifndef RVB_PAIR_COLD
 #define RVB_PAIR_COLD 0
 #endif
+#define RVB_KEY_RUN 32u      // grouping keys per run: 32 x 2 bytes = one 64-byte segment
 __device__ __forceinline__ uint32_t lane_id_here()
 {
     uint32_t lane;      // (volatile: recomputed where it is used instead of being kept in a register across the traversal loop)
@@ -795,6 +796,24 @@ struct PathJob {
     uint32_t skip;                       // own-plane subtree of the triangle the current segment starts on (TriShade, bvh.h)
     bool unit;                           // the ray's direction has unit length (the own-plane rule is derived for |d| = 1)
     float * cold;                        // COLD: this workgroup's [5][64] words in LDS
+    uint16_t * key_rows;                 // key runs (TraceArgs::sort_keys16): this workgroup's [rays][RVB_KEY_RUN] 16-bit keys in LDS
+
+    // Record-grouping keys as 64-byte RUNS.  The grouping key of a record (the leaf position of the triangle hit, 16 significant
+    // bits) used to leave as one 4-byte store per record, 8 KB apart in a ray's row: 51 MB of keys cost 0.4 GB of HBM writes (a
+    // partial-line write each; WRITE_SIZE 1.29 GB per launch for 0.87 GB of records and keys).  Now lane 1 of the ray parks the
+    // 16-bit key in LDS and, every RVB_KEY_RUN bounces, the ray's lanes write the run as whole 16-byte pieces of one 64-byte segment.
+    __device__ __forceinline__ uint16_t * key_row() const { return key_rows + (lane_id_here() >> (LANES == 4 ? 2 : 1)) * RVB_KEY_RUN; }
+    __device__ __forceinline__ void flush_key_run(const uint16_t * row, uint64_t first_record) const
+    {
+        const uint4 * src = reinterpret_cast<const uint4 *>(row);
+        uint4 * dst = reinterpret_cast<uint4 *>(a.sort_keys16 + first_record);
+        if (LANES == 4) {
+            dst[c] = src[c];
+        } else {
+            dst[2 * c] = src[2 * c];
+            dst[2 * c + 1] = src[2 * c + 1];
+        }
+    }
 
     __device__ __forceinline__ uint32_t skip_ref() const { return skip; }
     __device__ __forceinline__ bool next(v3 & o_, v3 & d_, float & tmax)
@@ -857,8 +876,14 @@ struct PathJob {
             store_stream(reinterpret_cast<float4 *>(a.impulses + record) + c + 2, c == 0 ? make_float4(p.x, p.y, p.z, diff) : tail);
         if (c == 0 && index < RVB_NUM_IMAGE_SOURCE - 1)
             a.early[ray * (RVB_NUM_IMAGE_SOURCE - 1) + index] = h.tri;
-        if (c == 1 && a.sort_keys)
-            a.sort_keys[record] = __float_as_uint(sk.w);               // the triangle's position in leaf order (rvb_set_scene put it there)
+        if (a.sort_keys16) {                                         // (wave-uniform) keys leave in runs, see flush_key_run
+            uint16_t * row = key_row();
+            const uint32_t at = index & (RVB_KEY_RUN - 1u);
+            if (c == 1) row[at] = (uint16_t) (__float_as_uint(sk.w) >> a.key_shift);      // the triangle's position in leaf order (rvb_set_scene put it there)
+            if (at == RVB_KEY_RUN - 1u) flush_key_run(row, record - at);
+        } else if (c == 1 && a.sort_keys) {
+            a.sort_keys[record] = __float_as_uint(sk.w);
+        }
 #if RVB_PROBE_NO_STORES
         }
 #endif
@@ -872,6 +897,41 @@ struct PathJob {
         ++index;
     }
 };
+
+// After the traversal: an escaped ray leaves its remaining slots zero-filled (reference rayverb.cpp:600-603 zero-fills the whole
+// buffer before every launch; here only the few slots that need it are written) and their grouping keys "no record".
+template <class Job, int LANES>
+__device__ __forceinline__ void finish_escaped_ray(const TraceArgs & a, Job & job, const uint64_t ray)
+{
+    if (job.index >= a.nreflections)
+        return;
+    for (uint32_t i = job.index; i < a.nreflections; ++i) {
+        const uint64_t record = ray * a.nreflections + i;
+        store_stream(reinterpret_cast<float4 *>(a.impulses + record) + job.c, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+        if (LANES == 2)
+            store_stream(reinterpret_cast<float4 *>(a.impulses + record) + job.c + 2, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+        if (job.c == 1 && a.sort_keys)
+            a.sort_keys[record] = NONE;
+    }
+    if (a.sort_keys16) {
+        // the run the ray was in: its remaining keys become "no record", then it leaves like any other; whole runs after it directly
+        uint16_t * row = job.key_row();
+        uint32_t i = job.index;
+        const uint32_t at = i & (RVB_KEY_RUN - 1u);
+        if (at) {
+            if (job.c == 1)
+                for (uint32_t k = at; k < RVB_KEY_RUN; ++k) row[k] = 0xFFFFu;
+            job.flush_key_run(row, ray * a.nreflections + (i - at));
+            i += RVB_KEY_RUN - at;
+        }
+        const uint4 none = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        for (; i < a.nreflections; i += RVB_KEY_RUN) {
+            uint4 * dst = reinterpret_cast<uint4 *>(a.sort_keys16 + ray * a.nreflections + i);
+            if (LANES == 4) dst[job.c] = none;
+            else { dst[2 * job.c] = none; dst[2 * job.c + 1] = none; }
+        }
+    }
+}
 
 // 64 VGPRs = 8 waves per SIMD: one resident round holds 8 x 1024 x 16 = 131 072 rays, so the 125 k rays per GPU of
 // workload C3 still run as one round (at 72 VGPRs / 7 waves they took 5.1 ms instead of 4.3 ms).
@@ -910,7 +970,8 @@ __global__ __launch_bounds__(WAVE, WAVES) void path_kernel(TraceArgs a)
     const float4 d4 = a.directions[local];
     const float len2 = d4.x * d4.x + d4.y * d4.y + d4.z * d4.z;
     PathJob<SURF_LDS> job = {a, (uint32_t) ray, threadIdx.x & 3u, source, mk3(d4.x, d4.y, d4.z), 0.0f,
-                   make_float4(1.0f, 1.0f, 1.0f, 1.0f), 0u, true, surf_lds, pair + 1u, RVB_BVH_EMPTY, fabsf(len2 - 1.0f) < 1e-3f, nullptr};
+                   make_float4(1.0f, 1.0f, 1.0f, 1.0f), 0u, true, surf_lds, pair + 1u, RVB_BVH_EMPTY, fabsf(len2 - 1.0f) < 1e-3f, nullptr,
+                   reinterpret_cast<uint16_t *>(stack_lds + a.stack_entries * QUADS_PER_BLOCK + 16u * a.lds_surfaces + (RVB_LDS_NODES * 16u))};
 #if RVB_PATH_JOBS == 2
 #if RVB_LDS_NODES
     traverse_jobs_vote(a.scene, stack_lds + q, job, lds_nodes);
@@ -928,14 +989,7 @@ __global__ __launch_bounds__(WAVE, WAVES) void path_kernel(TraceArgs a)
         job.done(hit, h);
     }
 #endif
-    // An escaped ray leaves its remaining slots zero-filled (reference rayverb.cpp:600-603 zero-fills the
-    // whole buffer before every launch; here only the few slots that need it are written).
-    for (uint32_t i = job.index; i < a.nreflections; ++i) {
-        const uint64_t record = ray * a.nreflections + i;
-        store_stream(reinterpret_cast<float4 *>(a.impulses + record) + job.c, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-        if (job.c == 1 && a.sort_keys)
-            a.sort_keys[record] = NONE;
-    }
+    finish_escaped_ray<PathJob<SURF_LDS>, 4>(a, job, ray);
     if (job.c == 0)
         atomicAdd(a.executed, (unsigned long long) job.index);
 }
@@ -982,27 +1036,16 @@ __device__ __forceinline__ void path_pair_body(const TraceArgs & a, const uint32
         cold[256 + threadIdx.x] = 0.0f;
     }
     PathJob<SURF_LDS, 2, RVB_PAIR_COLD != 0> job = {a, (uint32_t) ray, threadIdx.x & 1u, source, mk3(d4.x, d4.y, d4.z), 0.0f,
-                   make_float4(1.0f, 1.0f, 1.0f, 1.0f), 0u, true, surf_lds, pair + 1u, RVB_BVH_EMPTY, fabsf(len2 - 1.0f) < 1e-3f, cold};
+                   make_float4(1.0f, 1.0f, 1.0f, 1.0f), 0u, true, surf_lds, pair + 1u, RVB_BVH_EMPTY, fabsf(len2 - 1.0f) < 1e-3f, cold,
+                   reinterpret_cast<uint16_t *>(cold + (RVB_PAIR_COLD ? 5u * WAVE : 0u))};
 #if RVB_LDS_NODES
     traverse_pairs_vote(a.scene, stack_lds + q, job, lds_nodes);
 #else
     traverse_pairs_vote(a.scene, stack_lds + q, job);
 #endif
-    for (uint32_t i = job.index; i < a.nreflections; ++i) {       // an escaped ray's remaining slots (as in path_kernel)
-        const uint64_t record = ray * a.nreflections + i;
-        store_stream(reinterpret_cast<float4 *>(a.impulses + record) + job.c, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-        store_stream(reinterpret_cast<float4 *>(a.impulses + record) + job.c + 2, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-        if (job.c == 1 && a.sort_keys)
-            a.sort_keys[record] = NONE;
-    }
+    finish_escaped_ray<PathJob<SURF_LDS, 2, RVB_PAIR_COLD != 0>, 2>(a, job, ray);
     if (job.c == 0)
         atomicAdd(a.executed, (unsigned long long) job.index);
-}
-
-template <bool SURF_LDS>
-__global__ __launch_bounds__(WAVE, RVB_PAIR_WAVES) void path_pair_kernel(TraceArgs a)
-{
-    path_pair_body<SURF_LDS>(a, blockIdx.x);
 }
 
 // Several traces (contexts: their own rays, buffers, source and microphone) in ONE launch.  Two path kernels launched side by side
@@ -1505,14 +1548,15 @@ __global__ __launch_bounds__(WAVE, RVB_SHADOW_PAIR_WAVES) void shadow_pair_kerne
 // LDS of a quad kernel's single-wave workgroup: the traversal stack, then (optionally) the surface table
 static size_t quad_kernel_lds_bytes(const TraceArgs & a)
 {
-    return a.stack_entries * QUADS_PER_BLOCK * sizeof(uint32_t) + (size_t) a.lds_surfaces * sizeof(rvb_surface) + RVB_LDS_NODES * 64u;
+    return a.stack_entries * QUADS_PER_BLOCK * sizeof(uint32_t) + (size_t) a.lds_surfaces * sizeof(rvb_surface) + RVB_LDS_NODES * 64u
+           + (a.sort_keys16 ? QUADS_PER_BLOCK * RVB_KEY_RUN * sizeof(uint16_t) : 0u);
 }
 
 // LDS of the two-lane path kernel's single-wave workgroup: stack, surface table, (experiment: top nodes), the lanes' cold words
 static size_t rvb_pair_lds_bytes(const TraceArgs & a)
 {
     return a.stack_entries * PAIRS_PER_BLOCK * sizeof(uint32_t) + (size_t) a.lds_surfaces * sizeof(rvb_surface) + RVB_LDS_NODES * 64u
-           + (RVB_PAIR_COLD ? 5u * WAVE * sizeof(float) : 0u);
+           + (RVB_PAIR_COLD ? 5u * WAVE * sizeof(float) : 0u) + (a.sort_keys16 ? PAIRS_PER_BLOCK * RVB_KEY_RUN * sizeof(uint16_t) : 0u);
 }
 
 uint32_t rvb_lds_surfaces(uint32_t stack_entries, uint64_t nsurfaces)
@@ -1545,10 +1589,9 @@ void rvb_launch_path(const TraceArgs & a, hipStream_t s)
 {
     if (a.nrays == 0) return;
     if (a.path_lanes == 2) {
-        const unsigned blocks = (unsigned) ((a.nrays + PAIRS_PER_BLOCK - 1) / PAIRS_PER_BLOCK);
-        const size_t lds = rvb_pair_lds_bytes(a);
-        if (a.lds_surfaces) hipLaunchKernelGGL(path_pair_kernel<true>, dim3(blocks), dim3(WAVE), lds, s, a);
-        else hipLaunchKernelGGL(path_pair_kernel<false>, dim3(blocks), dim3(WAVE), lds, s, a);
+        // one trace through the group kernel: the form that takes its arguments from the group block needs 80 registers and no scratch
+        // (six waves per SIMD); a kernel of its own with TraceArgs by value came out at 86 once the key runs were added
+        rvb_launch_path_group(&a, 1, s);
         return;
     }
     const unsigned blocks = (unsigned) ((a.nrays + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK);

@@ -49,7 +49,7 @@ def main():
                            "-fhip-fp32-correctly-rounded-divide-sqrt", "-munsafe-fp-atomics", "-fno-slp-vectorize", "--cuda-device-only",
                            "-DRVB_ISA_MARKS=1", "-S", "-o", asm, os.path.join(PKG, "csrc", "trace_kernels.hip")], cwd=PKG)
     text = open(asm).read()
-    start = text.index("_ZN12_GLOBAL__N_116path_pair_kernelILb1EEEv9TraceArgs:")
+    start = text.index("_ZN12_GLOBAL__N_122path_pair_group_kernelILb1EEEvNS_10TraceGroupE:")
     body = text[start:text.index("s_endpgm", start)]
     blocks, current = collections.OrderedDict(), None
     for line in body.splitlines():
