@@ -8,7 +8,7 @@ import csv
 import sys
 from collections import Counter, defaultdict
 
-NAMES = ["path_pair_group_kernel", "path_pair_kernel", "path_kernel", "shadow_pair_kernel", "shadow_kernel", "image_kernel", "ordered_sum_kernel", "bin_keys_kernel",
+NAMES = ["path_pair_group_kernel", "path_pair_kernel", "path_kernel", "shadow_pair_kernel", "shadow_kernel", "image_plan_kernel", "image_check_kernel", "ordered_sum_hrtf_kernel", "ordered_sum_kernel", "bin_keys_hrtf_kernel", "bin_keys_kernel",
          "bin_starts_kernel", "radix_sort_onesweep_iteration", "radix_sort_onesweep_global_offsets", "histogram_fast_kernel",
          "histogram_transpose_kernel", "time_range_kernel", "fillBuffer", "copyBuffer"]
 
