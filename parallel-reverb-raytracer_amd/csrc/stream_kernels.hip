@@ -278,12 +278,11 @@ __global__ __launch_bounds__(256) void time_range_kernel(ModelDev m, const float
         if (!nz)
             continue;           // attenuated impulse is {0, 0}: no part in findPredelay / maxtime
         const v3 pos = mk3(px, py, pz);
-        const uint32_t nch = m.hrtf ? 2u : 1u;   // speaker channels all keep the input time
-        for (uint32_t ch = 0; ch < nch; ++ch) {
-            const float t = attenuated_time(m, ch, pos, time);
-            if (t != 0.0f) tmin = fminf(tmin, t);
-            tmax = fmaxf(tmax, t);
-        }
+        // speaker channels all keep the input time; of the two ears, the quad's even lanes take the left one and the odd lanes the
+        // right one (the wave-wide reduction below joins them): one time shift — two square roots — per lane instead of two
+        const float t = attenuated_time(m, q & 1u, pos, time);
+        if (t != 0.0f) tmin = fminf(tmin, t);
+        tmax = fmaxf(tmax, t);
     }
     for (int off = 32; off > 0; off >>= 1) {
         tmin = fminf(tmin, __shfl_xor(tmin, off));
@@ -690,7 +689,11 @@ void rvb_launch_attenuate(const AttenuationModel & m, uint32_t channel, const rv
 void rvb_launch_time_range(const AttenuationModel & m, const rvb_impulse * in, uint64_t n, uint32_t * range, hipStream_t s)
 {
     if (n == 0) return;
-    hipLaunchKernelGGL(time_range_kernel, dim3(stream_blocks(n * 4, 256)), dim3(256), 0, s, make_model(m),
+    // Every wave ends with two reads of the same two result words (and an atomic when it can still move them): with one workgroup
+    // per 4 KiB — the launch shape the other streaming kernels want — that is 1.6 M reads of one line, which, not HBM, then sets the
+    // kernel's time (0.34 ms at 12.8 M impulses; 0.17 ms with 2 048 grid-strided workgroups, 0.18 with 8 192, 0.25 with 65 536).
+    static const unsigned cap = getenv("RVB_TIME_RANGE_BLOCKS") ? (unsigned) atoi(getenv("RVB_TIME_RANGE_BLOCKS")) : 2048u;
+    hipLaunchKernelGGL(time_range_kernel, dim3(std::min(stream_blocks(n * 4, 256), cap ? cap : 2048u)), dim3(256), 0, s, make_model(m),
                        reinterpret_cast<const float4 *>(in), n, range);
 }
 
