@@ -86,6 +86,7 @@ struct rvb_ctx {
     unsigned char * small_host = nullptr;       // [kSmallBytes]
     rvb_image_candidate * first_candidates = nullptr;   // [kFirstCandidates], behind small_host in the same block
     bool small_valid = false;
+    bool stamps_cleared = false;
     std::vector<Timing> timings;
     std::vector<hipEvent_t> event_pool;
     size_t events_used = 0;
@@ -522,7 +523,12 @@ static int trace_prepare(rvb_ctx * ctx, const float * mics, const float * source
 
     // diagnostic builds (RVB_STAMPS): [0..15] path_kernel, [16..31] shadow_kernel
     RVB_HIP(ctx, ctx->stamps.ensure(32 * sizeof(unsigned long long)));
-    RVB_HIP(ctx, hipMemsetAsync(ctx->stamps.p, 0, 32 * sizeof(unsigned long long), ctx->stream));
+    // (zeroed per trace only where a diagnostic build may write them: one tiny fill kernel less on the stream of every shipped trace)
+    static const bool stamps_on = getenv("RVB_STAMPS") != nullptr;
+    if (stamps_on || !ctx->stamps_cleared) {
+        RVB_HIP(ctx, hipMemsetAsync(ctx->stamps.p, 0, 32 * sizeof(unsigned long long), ctx->stream));
+        ctx->stamps_cleared = true;
+    }
     a.scene.stamps = ctx->stamps.as<unsigned long long>();
 
     // diagnostic only (timing probes whose path kernel leaves records unwritten, -DRVB_PROBE_NO_STORES): start from invalid records
