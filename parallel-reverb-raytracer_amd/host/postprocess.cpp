@@ -98,20 +98,43 @@ struct BandpassWindowedSinc : Bandpass {
     void filter(vector<float> & data) { data = convolveScaled(kernel, data, KERNEL_LENGTH + data.size() - 1); }
 };
 
-// RBJ cookbook band-pass (reference filters.cpp:198-223)
+// Second-order sections as {b0, b1, b2, a1, a2}, already divided by a0.
+struct Section { double b0, b1, b2, a1, a2; };
+
+// Constant-skirt band-pass of the Audio-EQ cookbook between two corner frequencies (what the reference designs at filters.cpp:198-223):
+// centre = geometric mean of the corners, width in octaves, Q from the width at the centre's digital frequency.
+Section bandpassSection(float corner_lo, float corner_hi, float sample_rate)
+{
+    const double centre = std::sqrt(corner_lo * corner_hi);
+    const double w0 = 2 * M_PI * centre / sample_rate;
+    const double cos_w0 = std::cos(w0), sin_w0 = std::sin(w0);
+    const double octaves = std::log2(corner_hi / corner_lo);
+    const double quality = sin_w0 / (std::log(2) * octaves * w0);
+    const double half_width = sin_w0 * std::sinh(1 / (2 * quality));
+    const double gain = 1 / (1 + half_width);                      // 1 / a0
+    return Section{gain * half_width, gain * 0, gain * -half_width, gain * (-2 * cos_w0), gain * (1 - half_width)};
+}
+
+// Second-order Butterworth low-pass / high-pass by the bilinear transform with k = cot(pi fc / fs) (reference filters.cpp:225-266)
+struct ButterworthPair { Section low, high; };
+double cotangentOfHalfDigitalFrequency(double cutoff, double sample_rate)
+{
+    const double half = M_PI * cutoff / sample_rate;
+    return std::cos(half) / std::sin(half);
+}
+Section butterworth(double cutoff, double sample_rate, bool highpass)
+{
+    const double k = cotangentOfHalfDigitalFrequency(cutoff, sample_rate);
+    const double k2 = k * k, damping = k * std::sqrt(2);
+    const double a0 = k2 + damping + 1;
+    const double a1 = (-2 * (k2 - 1)) / a0, a2 = (k2 - damping + 1) / a0;
+    return highpass ? Section{k2 / a0, (-2 * k2) / a0, k2 / a0, a1, a2} : Section{1 / a0, 2 / a0, 1 / a0, a1, a2};
+}
+
+void load(RayverbFiltering::Biquad & filter, const Section & s) { filter.setParams(s.b0, s.b1, s.b2, s.a1, s.a2); }
+
 struct OnepassBandpassBiquad : Bandpass, RayverbFiltering::Biquad {
-    void setParams(float lo, float hi, float sr)
-    {
-        const double c = std::sqrt(lo * hi);
-        const double omega = 2 * M_PI * c / sr;
-        const double cs = std::cos(omega);
-        const double sn = std::sin(omega);
-        const double bandwidth = std::log2(hi / lo);
-        const double Q = sn / (std::log(2) * bandwidth * omega);
-        const double alpha = sn * std::sinh(1 / (2 * Q));
-        const double nrm = 1 / (1 + alpha);
-        Biquad::setParams(nrm * alpha, nrm * 0, nrm * -alpha, nrm * (-2 * cs), nrm * (1 - alpha));
-    }
+    void setParams(float lo, float hi, float sr) { load(*this, bandpassSection(lo, hi, sr)); }
     void filter(vector<float> & data) { onepass(data); }
 };
 
@@ -119,27 +142,13 @@ struct TwopassBandpassBiquad : OnepassBandpassBiquad {
     void filter(vector<float> & data) { twopass(data); }
 };
 
-double getC(double co, double sr)
-{
-    const double wcT = M_PI * co / sr;
-    return std::cos(wcT) / std::sin(wcT);
-}
-
-// zero-phase second-order Butterworth low-pass + high-pass (reference filters.cpp:241-266)
+// zero-phase band-pass from a low-pass at the upper corner and a high-pass at the lower one, each run forwards and backwards
 struct LinkwitzRiley : Bandpass {
     RayverbFiltering::Biquad lopass, hipass;
-    void setParams(float l, float h, float s)
+    void setParams(float lower, float upper, float sample_rate)
     {
-        {
-            const double c = getC(h, s);
-            const double a0 = c * c + c * std::sqrt(2) + 1;
-            lopass.setParams(1 / a0, 2 / a0, 1 / a0, (-2 * (c * c - 1)) / a0, (c * c - c * std::sqrt(2) + 1) / a0);
-        }
-        {
-            const double c = getC(l, s);
-            const double a0 = c * c + c * std::sqrt(2) + 1;
-            hipass.setParams((c * c) / a0, (-2 * c * c) / a0, (c * c) / a0, (-2 * (c * c - 1)) / a0, (c * c - c * std::sqrt(2) + 1) / a0);
-        }
+        load(lopass, butterworth(upper, sample_rate, false));
+        load(hipass, butterworth(lower, sample_rate, true));
     }
     void filter(vector<float> & data)
     {
