@@ -1104,6 +1104,7 @@ int rvb_device_free(rvb_ctx * ctx, void * d_ptr)
     if (!d_ptr) return RVB_OK;
     RVB_BIND(ctx);
     RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RVB_HIP(ctx, hipStreamSynchronize(ctx->export_stream));       // ... or a copy out of it
     RVB_HIP(ctx, hipFree(d_ptr));
     return RVB_OK;
 }
@@ -1230,6 +1231,7 @@ int rvb_host_free(rvb_ctx * ctx, void * host_ptr)
     if (!host_ptr) return RVB_OK;
     RVB_BIND(ctx);
     RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RVB_HIP(ctx, hipStreamSynchronize(ctx->export_stream));       // a copy into this block may still be on its way
     RVB_HIP(ctx, hipHostFree(host_ptr));
     return RVB_OK;
 }
