@@ -525,3 +525,42 @@ def test_fused_ir_exact_and_fast_modes(ctx, oracle, model, trim):
             np.add.at(absum[b], bins, np.abs(chans[ch]["volume"][:, b].astype(np.float64)))
         bound = 1e-5 * np.abs(exact[ch]) + count[None, :] * 2.0 ** -23 * absum + 1e-30
         assert (np.abs(fast[ch].astype(np.float64) - exact[ch]) <= bound).all(), (model, trim, ch)
+
+
+def test_histogram_leaves_for_pinned_host_memory_on_the_export_stream(ctx):
+    """rvb_host_alloc + rvb_copy_to_pinned_host_async + rvb_synchronize_exports: the copy starts behind the binning that fills the
+    device histogram, a second trace enqueued right behind it does not disturb it, and what lands is what rvb_ir_download returns."""
+    import ctypes
+    import torch
+    from parallel_reverb_raytracer_amd import capi
+    scene, info = scenes.cathedral(3000)
+    mic, src = info["mic"], info["source"]
+    ctx.set_scene(scene)
+    ctx.raytrace(mic, src, scenes.sphere_directions(4096, seed=31), 32, AIR_COEFFICIENTS)
+    images = ctx.get_raw_images(False)
+    ctx.ir_configure_speakers(mic, [(-1, 0, -1), (1, 0, -1)], [0.5, 0.5], capi.IR_ALL, images)
+    want = ctx.ir_download(True, 44100.0, capi.IR_EXACT)
+    lo, hi = ctx.ir_time_range()
+    nbins = ctx.ir_bins(hi, lo, 44100.0)
+    assert want.shape == (2, 8, nbins)
+    nbytes = want.nbytes
+    host = ctypes.c_void_p()
+    ctx._check(ctx.lib.rvb_host_alloc(ctx.handle, ctypes.c_uint64(nbytes), ctypes.byref(host)))
+    try:
+        landed = np.ctypeslib.as_array(ctypes.cast(host, ctypes.POINTER(ctypes.c_float)), shape=(2, 8, nbins))
+        landed[...] = np.nan
+        hist = torch.zeros((2, 8, nbins), device="cuda", dtype=torch.float32)
+        ctx.ir_accumulate_tensor(lo, 44100.0, nbins, capi.IR_EXACT, hist)
+        ctx._check(ctx.lib.rvb_copy_to_pinned_host_async(ctx.handle, host, ctypes.c_void_p(hist.data_ptr()), ctypes.c_uint64(nbytes)))
+        ctx.trace(mic, src, 32, AIR_COEFFICIENTS)                   # the next trace does not wait for the link, nor the copy for the trace
+        ctx.synchronize_exports()
+        assert np.array_equal(landed, want)
+        ctx.synchronize()
+        # an odd byte count and a pageable destination take the runtime's plain copy: same bytes
+        plain = np.full(nbins * 16 - 3, np.nan, dtype=np.float32)
+        ctx._check(ctx.lib.rvb_copy_to_pinned_host_async(ctx.handle, plain.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(hist.data_ptr()),
+                                                         ctypes.c_uint64(plain.nbytes)))
+        ctx.synchronize_exports()
+        assert np.array_equal(plain, want.reshape(-1)[:plain.shape[0]])
+    finally:
+        ctx._check(ctx.lib.rvb_host_free(ctx.handle, host))
