@@ -25,8 +25,20 @@ def main():
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 16
     events = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r["Stream_Id"]) for r in rows)
     paths = [e for e in events if e[2] in ("path_pair_group_kernel", "path_pair_kernel", "path_kernel")]
-    region = paths[-(steps // 2 if paths and paths[-1][2] == "path_pair_group_kernel" else steps):]      # (a group kernel carries two traces)
-    t0, t1 = region[0][0], max(e[1] for e in events)
+    # the timed region's path kernels are the two-trace group launches (grid > one trace's waves); bench.py traces single IRs before and
+    # after it (solo passes, the check of the last histogram), which do not belong to the region
+    grid = {(int(r["Start_Timestamp"]), r["Kernel_Name"]): int(r["Grid_Size_X"]) for r in rows}
+    widest = max((grid.get((e[0], n), 0) for e in paths for n in [next(r["Kernel_Name"] for r in rows if int(r["Start_Timestamp"]) == e[0])]), default=0)
+    groups = [e for e in paths if grid.get((e[0], next(r["Kernel_Name"] for r in rows if int(r["Start_Timestamp"]) == e[0])), 0) == widest]
+    if len(groups) >= steps // 2 and widest:
+        region = groups[-(steps // 2):]
+        t1 = region[-1][1] + 5_000_000                    # the last group's shadow / binning stages follow its path kernel within a few ms
+        events = [e for e in events if e[0] <= t1]
+        t1 = max(e[1] for e in events)
+    else:
+        region = paths[-steps:]
+        t1 = max(e[1] for e in events)
+    t0 = region[0][0]
     print("timed region: %d path kernels for %d IRs, %.2f ms = %.3f ms per IR" % (len(region), steps, (t1 - t0) / 1e6, (t1 - t0) / 1e6 / steps))
     print("path kernels (start ms, duration ms, stream):")
     for s, e, n, st in region:
