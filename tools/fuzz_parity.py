@@ -46,6 +46,9 @@ def main():
         mic = rng.uniform(-extent, extent, 3) * (0.3, 0.1, 0.3) + (0, 2.0 if kind else 0.0, 0)
         src = rng.uniform(-extent, extent, 3) * (0.3, 0.1, 0.3) + (0, 2.5 if kind else 0.0, 0)
         nrays, nrefl = int(rng.integers(1, 30000 if big else 3000)), int(rng.integers(1, 120 if big else 40))
+        if os.environ.get("FUZZ_REFLECTION_MULTIPLE"):      # e.g. 32: whole runs of grouping keys (the path kernels' LDS key runs, escaped rays included)
+            m = int(os.environ["FUZZ_REFLECTION_MULTIPLE"])
+            nrefl = max(m, (nrefl + m - 1) // m * m)
         dirs = scenes.sphere_directions(nrays, seed=case + 1)
         ctx.set_scene(scene)
         ctx.raytrace(mic, src, dirs, nrefl, dtypes.AIR_COEFFICIENTS)
