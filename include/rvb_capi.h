@@ -92,6 +92,10 @@ int rvb_set_directions_device(rvb_ctx * ctx, const void * d_directions, uint64_t
  * flight fill the chip without the extra waves (csrc/trace_kernels.hip, rvb_path_lanes_for).  No reference counterpart: the
  * reference runs one 4096-ray group at a time (rayverb.cpp:586-591). */
 int rvb_set_concurrent_traces(rvb_ctx * ctx, uint32_t traces);
+/* Measurement / test hook, never a change of results: the path kernel of this context's traces with `lanes` lanes per ray — 4 (path_kernel),
+ * 2 (path_pair_kernel), 1 (path_lane_kernel) — whatever the launch size; 0 (default) lets every launch choose (rvb_path_lanes_for).  The three
+ * kernels write the same bytes (tests/test_gpu_parity.py runs every trace case with each). */
+int rvb_set_path_lanes(rvb_ctx * ctx, uint32_t lanes);
 
 /* ---- trace: replaces Raytracer::raytrace (rayverb.cpp:538-685) + kernel raytrace
  * (kernel.cpp:304-503).  Traces exactly nrays rays (all at once, no 4096-ray groups) for

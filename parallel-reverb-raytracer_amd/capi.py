@@ -24,7 +24,7 @@ IR_FAST, IR_EXACT = 0, 1
 # every symbol include/rvb_capi.h declares
 SYMBOLS = [
     "rvb_create", "rvb_destroy", "rvb_last_error", "rvb_synchronize", "rvb_wait_for_event", "rvb_device_info",
-    "rvb_set_scene", "rvb_scene_info", "rvb_set_directions", "rvb_set_directions_device", "rvb_set_concurrent_traces", "rvb_trace", "rvb_trace_group",
+    "rvb_set_scene", "rvb_scene_info", "rvb_set_directions", "rvb_set_directions_device", "rvb_set_concurrent_traces", "rvb_set_path_lanes", "rvb_trace", "rvb_trace_group",
     "rvb_trace_pairs", "rvb_ir_select_pair",
     "rvb_get_diffuse", "rvb_diffuse_device", "rvb_get_direct", "rvb_get_image_candidates", "rvb_merge_images",
     "rvb_attenuate_speaker", "rvb_attenuate_speaker_device", "rvb_attenuate_hrtf", "rvb_attenuate_hrtf_device", "rvb_flatten",
@@ -187,6 +187,10 @@ class Context:
     def set_concurrent_traces(self, traces):
         """Hint: traces of this size the caller keeps in flight on the device at a time (rvb_set_concurrent_traces)."""
         self._check(self.lib.rvb_set_concurrent_traces(self.handle, ctypes.c_uint32(int(traces))))
+
+    def set_path_lanes(self, lanes):
+        """Test / measurement hook: lanes per ray of this context's path kernel (4, 2, 1; 0 = chosen per launch).  Same bytes either way."""
+        self._check(self.lib.rvb_set_path_lanes(self.handle, ctypes.c_uint32(int(lanes))))
 
     def trace(self, mic, source, nreflections, air, ray_offset=0):
         self._check(self.lib.rvb_trace(self.handle, _f3(mic), _f3(source), _u64(nreflections), _f8(air), _u64(ray_offset)))

@@ -65,6 +65,7 @@ struct rvb_ctx {
     const float4 * directions = nullptr;
     uint64_t nrays = 0;
     uint32_t concurrent_traces = 1;             // rvb_set_concurrent_traces
+    uint32_t path_lanes = 0;                    // rvb_set_path_lanes: 0 = chosen per launch (rvb_path_lanes_for)
     bool traced = false;
     uint64_t nreflections = 0;
     float mic[3] = {0, 0, 0};
@@ -404,6 +405,14 @@ int rvb_set_concurrent_traces(rvb_ctx * ctx, uint32_t traces)
     return RVB_OK;
 }
 
+int rvb_set_path_lanes(rvb_ctx * ctx, uint32_t lanes)
+{
+    if (!ctx) return RVB_ERR_INVALID;
+    if (lanes != 0 && lanes != 1 && lanes != 2 && lanes != 4) return fail(ctx, RVB_ERR_INVALID, "rvb_set_path_lanes: 0 (automatic), 1, 2 or 4");
+    ctx->path_lanes = lanes;
+    return RVB_OK;
+}
+
 // A trace in three steps — buffers, fills and kernel arguments; the path kernel; everything after it — so that rvb_trace_group can put
 // the path kernels of several contexts into ONE launch.
 struct TracePlan {
@@ -516,7 +525,7 @@ static int trace_prepare(rvb_ctx * ctx, const float * mics, const float * source
     a.lds_surfaces = rvb_lds_surfaces(ctx->stack_need, ctx->nsurfaces);
     a.scene_nodes = (uint32_t) ctx->nnodes;
     // (rays_in_flight: what a group launch carries in all; 0 = this trace alone, times the caller's hint)
-    a.path_lanes = rays_in_flight ? rvb_path_lanes_for(rays_in_flight, 1) : rvb_path_lanes_for(nrays, ctx->concurrent_traces);
+    a.path_lanes = ctx->path_lanes ? ctx->path_lanes : (rays_in_flight ? rvb_path_lanes_for(rays_in_flight, 1) : rvb_path_lanes_for(nrays, ctx->concurrent_traces));
     a.ray_offset = ray_offset;
     for (int i = 0; i < 3; ++i) { a.mic[i] = mic[i]; a.source[i] = source[i]; ctx->mic[i] = mic[i]; }
     for (int i = 0; i < 8; ++i) a.air[i] = air_coefficient[i];
@@ -604,13 +613,16 @@ static int trace_finish(rvb_ctx * ctx, TracePlan & plan, const float * mics)
     return RVB_OK;
 }
 
+// the name a path launch is timed under: the kernel that ran (csrc/trace_kernels.hip, rvb_path_lanes_for)
+static const char * path_kernel_name(uint32_t lanes) { return lanes == 1 ? "path_lane_kernel" : (lanes == 2 ? "path_pair_kernel" : "path_kernel"); }
+
 static int trace_common(rvb_ctx * ctx, const float * mics, const float * sources, uint64_t npairs, uint64_t nreflections,
                         const float air_coefficient[8], uint64_t ray_offset)
 {
     TracePlan plan;
     int rc = trace_prepare(ctx, mics, sources, npairs, nreflections, air_coefficient, ray_offset, 0, plan);
     if (rc != RVB_OK) return rc;
-    ctx->begin_timing(plan.a.path_lanes == 2 ? "path_pair_kernel" : "path_kernel");
+    ctx->begin_timing(path_kernel_name(plan.a.path_lanes));
     rvb_launch_path(plan.a, ctx->stream);
     ctx->end_timing();
     return trace_finish(ctx, plan, mics);
@@ -634,11 +646,12 @@ int rvb_trace_group(rvb_ctx ** ctxs, uint64_t count, const float * mics, const f
                                      total_rays, plans[i]);
         if (rc != RVB_OK) return rc;
     }
-    // one launch for all of them when they can share a kernel: two lanes per ray, one device, one LDS layout
-    bool fused = count > 1 && plans[0].a.path_lanes == 2;
+    // one launch for all of them when they can share a kernel: one or two lanes per ray, one device, one LDS layout (stack depth, surfaces
+    // staged, key runs or not: the launch's LDS is laid out once for all its workgroups)
+    bool fused = count > 1 && plans[0].a.path_lanes <= 2;
     for (uint64_t i = 1; i < count && fused; ++i)
-        fused = ctxs[i]->device == ctxs[0]->device && plans[i].a.path_lanes == 2 && plans[i].a.stack_entries == plans[0].a.stack_entries
-                && plans[i].a.lds_surfaces == plans[0].a.lds_surfaces;
+        fused = ctxs[i]->device == ctxs[0]->device && plans[i].a.path_lanes == plans[0].a.path_lanes && plans[i].a.stack_entries == plans[0].a.stack_entries
+                && plans[i].a.lds_surfaces == plans[0].a.lds_surfaces && (plans[i].a.sort_keys16 != nullptr) == (plans[0].a.sort_keys16 != nullptr);
     for (uint64_t i = 0; i < count && fused; ++i) fused = plans[i].nrays > 0;
     if (fused) {
         rvb_ctx * lead = ctxs[0];
@@ -649,19 +662,19 @@ int rvb_trace_group(rvb_ctx ** ctxs, uint64_t count, const float * mics, const f
         }
         TraceArgs args[RVB_MAX_GROUP];
         for (uint64_t i = 0; i < count; ++i) args[i] = plans[i].a;
-        lead->begin_timing("path_pair_kernel");
+        lead->begin_timing(path_kernel_name(args[0].path_lanes));
         rvb_launch_path_group(args, (uint32_t) count, lead->stream);
         lead->end_timing();
         RVB_HIP(lead, hipEventRecord(lead->group_done, lead->stream));
         for (uint64_t i = 1; i < count; ++i) {
-            ctxs[i]->begin_timing("path_pair_kernel");              // (elapsed: from this stream's arrival to the end of the group's kernel)
+            ctxs[i]->begin_timing(path_kernel_name(args[0].path_lanes));   // (elapsed: from this stream's arrival to the end of the group's kernel)
             RVB_HIP(ctxs[i], hipStreamWaitEvent(ctxs[i]->stream, lead->group_done, 0));
             ctxs[i]->end_timing();
         }
     } else {
         for (uint64_t i = 0; i < count; ++i) {
             RVB_BIND(ctxs[i]);
-            ctxs[i]->begin_timing(plans[i].a.path_lanes == 2 ? "path_pair_kernel" : "path_kernel");
+            ctxs[i]->begin_timing(path_kernel_name(plans[i].a.path_lanes));
             rvb_launch_path(plans[i].a, ctxs[i]->stream);
             ctxs[i]->end_timing();
         }

@@ -880,7 +880,10 @@ struct PathJob {
             uint16_t * row = key_row();
             const uint32_t at = index & (RVB_KEY_RUN - 1u);
             if (c == 1) row[at] = (uint16_t) (__float_as_uint(sk.w) >> a.key_shift);      // the triangle's position in leaf order (rvb_set_scene put it there)
-            if (at == RVB_KEY_RUN - 1u) flush_key_run(row, record - at);
+            if (at == RVB_KEY_RUN - 1u) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // lane 1's 16-bit store before the 16-byte loads of the ray's other lane(s)
+                flush_key_run(row, record - at);
+            }
         } else if (c == 1 && a.sort_keys) {
             a.sort_keys[record] = __float_as_uint(sk.w);
         }
@@ -921,6 +924,7 @@ __device__ __forceinline__ void finish_escaped_ray(const TraceArgs & a, Job & jo
         if (at) {
             if (job.c == 1)
                 for (uint32_t k = at; k < RVB_KEY_RUN; ++k) row[k] = 0xFFFFu;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             job.flush_key_run(row, ray * a.nreflections + (i - at));
             i += RVB_KEY_RUN - at;
         }
@@ -1063,6 +1067,226 @@ __global__ __launch_bounds__(WAVE, RVB_PAIR_WAVES) void path_pair_group_kernel(T
     for (uint32_t k = 1; k < g.count; ++k)
         which += blockIdx.x >= g.first_block[k] ? 1u : 0u;
     path_pair_body<SURF_LDS>(g.trace[which], blockIdx.x - g.first_block[which]);
+}
+
+// ONE LANE PER RAY (path_lane_group_kernel, round 4): 64 rays per single-wave workgroup, every lane walks its own ray — it tests the
+// four children of its node and the up-to-four triangles of its leaf itself, nothing is exchanged between lanes, and the stack is the
+// lane's own column in LDS.  What the lanes of a pair (or quad) repeat per ray — the vote's state, the stack pointer, the child
+// keys, the lane exchange, the 64-bit key reductions — is paid once per ray, and a wave step serves 64 rays: tools/travforms.cpp
+// replays C2 at 29.3 node + 5.4 leaf + 2.7 shading wave steps per 64 ray-bounces (pairs: 28.5 + 5.2 + 2.6 per 32), i.e. a quarter to
+// a third fewer wave instructions per ray-bounce with the step costs of this kernel's ISA.  The price is half the waves again (100 k
+// rays are 1.5 waves per SIMD) and longer steps, so a launch is bound by the latency of one wave's chain unless about 400 k rays are
+// in flight: rvb_path_lanes_for picks it for group launches of that size only.  Same arithmetic, same records, same bytes as the
+// other two path kernels (tests/test_gpu_parity.py runs every trace case with all three).
+#define LANE_RAYS 64
+typedef __attribute__((address_space(3))) uint32_t * lds_u32_ptr;
+#ifndef RVB_LANE_WAVES
+#define RVB_LANE_WAVES 4            // waves per SIMD the register budget allows (128 VGPRs)
+#endif
+template <bool SURF_LDS>
+__device__ __forceinline__ void path_lane_body(const TraceArgs & a, const uint32_t block)
+{
+    // LDS of the workgroup: [stack_entries + 1][64] stack words (a lane's column; one slack row: pushes store first and advance if
+    // kept), the surface table, [64][RVB_KEY_RUN] 16-bit grouping keys (rvb_lane_lds_bytes)
+    extern __shared__ __attribute__((aligned(16))) uint32_t stack_lds[];
+    const uint32_t IDLE = 0xFFFFFFFEu;
+    const uint32_t lane = threadIdx.x;
+    const uint64_t ray = (uint64_t) block * LANE_RAYS + lane;
+    uint32_t * const after_stack = stack_lds + (a.stack_entries + 1u) * LANE_RAYS;
+    const lds_float4_ptr surf_lds = stage_surfaces(a, after_stack);
+    uint16_t * const key_row = reinterpret_cast<uint16_t *>(after_stack + 16u * a.lds_surfaces) + lane * RVB_KEY_RUN;
+    if (ray >= a.nrays)
+        return;
+    uint32_t pair = 0, local = (uint32_t) ray;
+    v3 o = ld3(a.source);
+    if (a.npairs > 1) {
+        pair = (uint32_t) ray / a.rays_per_pair;
+        local = (uint32_t) ray - pair * a.rays_per_pair;
+        const float4 s4 = a.pair_sources[pair];
+        o = mk3(s4.x, s4.y, s4.z);
+    }
+    const float4 d4 = a.directions[local];
+    v3 d = mk3(d4.x, d4.y, d4.z);
+    const bool unit = fabsf(d4.x * d4.x + d4.y * d4.y + d4.z * d4.z - 1.0f) < 1e-3f;
+    const uint32_t pair_tag = pair + 1u;
+    float4 vol_lo = make_float4(1.0f, 1.0f, 1.0f, 1.0f), vol_hi = vol_lo;      // kernel.cpp:322-323
+    float distance = 0.0f;
+    uint32_t index = 0, skip = RVB_BVH_EMPTY;
+
+    const char * node_base = reinterpret_cast<const char *>(a.scene.nodes);
+    const char * tri_base = reinterpret_cast<const char *>(a.scene.tris);
+    const float neg_cull = -a.scene.cull_abs, cull_scale = 1.0f + a.scene.cull_rel;
+    const unsigned long long NO_HIT_KEY = (0x7F800000ull << 32) | NONE;
+    const lds_u32_ptr bottom = (lds_u32_ptr) stack_lds + lane;
+    lds_u32_ptr sp = bottom;
+    float ix = 0.0f, iy = 0.0f, iz = 0.0f, oix = 0.0f, oiy = 0.0f, oiz = 0.0f;
+    uint32_t selx = 0, sely = 0, selz = 0;
+    unsigned long long best_key = NO_HIT_KEY;
+    uint32_t ref = IDLE;
+#define RVB_RESET_QUERY()                                                         \
+    {                                                                             \
+        ix = clamp_inv(d.x); iy = clamp_inv(d.y); iz = clamp_inv(d.z);            \
+        oix = o.x * ix; oiy = o.y * iy; oiz = o.z * iz;                           \
+        selx = slab_selector(ix); sely = slab_selector(iy); selz = slab_selector(iz); \
+        best_key = NO_HIT_KEY; sp = bottom; ref = 0;                              \
+    }
+    if (index < a.nreflections) RVB_RESET_QUERY()
+    for (;;) {
+        RVB_MARK("vote");
+        const unsigned long long m_node = __builtin_amdgcn_ballot_w64((int32_t) ref >= 0);
+        const unsigned long long m_done = __builtin_amdgcn_ballot_w64(ref == NONE);
+        const unsigned long long m_leaf = __builtin_amdgcn_ballot_w64((int32_t) ref < (int32_t) IDLE);
+        const int n_node = scalar_popcount(m_node), n_done = scalar_popcount(m_done), n_leaf = scalar_popcount(m_leaf);
+        if ((n_node | n_done | n_leaf) == 0)
+            break;
+        if (n_node >= n_leaf && n_node >= n_done) {
+            RVB_MARK("node");
+            if ((int32_t) ref >= 0) {
+                const uint4 * np = reinterpret_cast<const uint4 *>(node_base + ref);
+                const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+                const float limit = fmaf(__uint_as_float((uint32_t) (best_key >> 32)), cull_scale, a.scene.cull_abs);
+                float tn0, tn1, tn2, tn3;
+                const bool ok0 = slab_select(n0, ix, iy, iz, oix, oiy, oiz, selx, sely, selz, limit, neg_cull, skip, tn0);
+                const bool ok1 = slab_select(n1, ix, iy, iz, oix, oiy, oiz, selx, sely, selz, limit, neg_cull, skip, tn1);
+                const bool ok2 = slab_select(n2, ix, iy, iz, oix, oiy, oiz, selx, sely, selz, limit, neg_cull, skip, tn2);
+                const bool ok3 = slab_select(n3, ix, iy, iz, oix, oiy, oiz, selx, sely, selz, limit, neg_cull, skip, tn3);
+                // nearest hit child first, by the same (entry distance | child) keys as the other path kernels: the visiting order, and
+                // with it the culling, is theirs
+                const uint32_t key0 = ok0 ? ((__float_as_uint(fmaxf(tn0, 0.0f)) & ~3u) | 0u) : NONE;
+                const uint32_t key1 = ok1 ? ((__float_as_uint(fmaxf(tn1, 0.0f)) & ~3u) | 1u) : NONE;
+                const uint32_t key2 = ok2 ? ((__float_as_uint(fmaxf(tn2, 0.0f)) & ~3u) | 2u) : NONE;
+                const uint32_t key3 = ok3 ? ((__float_as_uint(fmaxf(tn3, 0.0f)) & ~3u) | 3u) : NONE;
+                const uint32_t kmin = min(min(key0, key1), min(key2, key3));
+                // the other hit children go on the stack in child order: store, then advance past the store if it is kept
+                *sp = n0.w; sp += (ok0 && key0 != kmin) ? LANE_RAYS : 0;
+                *sp = n1.w; sp += (ok1 && key1 != kmin) ? LANE_RAYS : 0;
+                *sp = n2.w; sp += (ok2 && key2 != kmin) ? LANE_RAYS : 0;
+                *sp = n3.w; sp += (ok3 && key3 != kmin) ? LANE_RAYS : 0;
+                if (kmin == NONE) {
+                    if (sp != bottom) { sp -= LANE_RAYS; ref = *sp; } else ref = NONE;
+                } else {
+                    const uint32_t lo = (kmin & 1u) ? n1.w : n0.w, hi = (kmin & 1u) ? n3.w : n2.w;
+                    ref = (kmin & 2u) ? hi : lo;
+                }
+            }
+        } else if (n_leaf >= n_done) {
+            RVB_MARK("leaf");
+            if ((int32_t) ref < (int32_t) IDLE) {
+                const uint32_t first = ref & 0x0FFFFFFFu;
+                const uint32_t count = ((ref >> 28) & 7u) + 1u;
+                const float4 * tp0 = reinterpret_cast<const float4 *>(tri_base + tri_byte_offset(first));
+                const float4 * tp1 = reinterpret_cast<const float4 *>(tri_base + tri_byte_offset(first + (1u < count ? 1u : 0u)));
+                const float4 * tp2 = reinterpret_cast<const float4 *>(tri_base + tri_byte_offset(first + (2u < count ? 2u : 0u)));
+                const float4 * tp3 = reinterpret_cast<const float4 *>(tri_base + tri_byte_offset(first + (3u < count ? 3u : 0u)));
+                float4 ta = tp0[0], tb = tp0[1], tc = tp0[2], ua = tp1[0], ub = tp1[1], uc = tp1[2];
+                float4 va = tp2[0], vb = tp2[1], vc = tp2[2], wa = tp3[0], wb = tp3[1], wc = tp3[2];
+                // all twelve loads leave before the first use (one round trip per leaf step, not four)
+                asm volatile("" : "+v"(ta.x), "+v"(tb.x), "+v"(tc.x), "+v"(ua.x), "+v"(ub.x), "+v"(uc.x),
+                                  "+v"(va.x), "+v"(vb.x), "+v"(vc.x), "+v"(wa.x), "+v"(wb.x), "+v"(wc.x));
+                const float dist0 = mt_intersect(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), o, d);
+                const float dist1 = mt_intersect(mk3(ua.x, ua.y, ua.z), mk3(ua.w, ub.x, ub.y), mk3(ub.z, ub.w, uc.x), o, d);
+                const float dist2 = mt_intersect(mk3(va.x, va.y, va.z), mk3(va.w, vb.x, vb.y), mk3(vb.z, vb.w, vc.x), o, d);
+                const float dist3 = mt_intersect(mk3(wa.x, wa.y, wa.z), mk3(wa.w, wb.x, wb.y), mk3(wb.z, wb.w, wc.x), o, d);
+                // kernel.cpp:180-188 — smallest distance wins, equal distances go to the lower index: one unsigned 64-bit key
+                const bool valid0 = dist0 > RVB_EPSILON, valid1 = 1u < count && dist1 > RVB_EPSILON;
+                const bool valid2 = 2u < count && dist2 > RVB_EPSILON, valid3 = 3u < count && dist3 > RVB_EPSILON;
+                const unsigned long long k0 = valid0 ? (((unsigned long long) __float_as_uint(dist0) << 32) | __float_as_uint(tc.y)) : NO_HIT_KEY;
+                const unsigned long long k1 = valid1 ? (((unsigned long long) __float_as_uint(dist1) << 32) | __float_as_uint(uc.y)) : NO_HIT_KEY;
+                const unsigned long long k2 = valid2 ? (((unsigned long long) __float_as_uint(dist2) << 32) | __float_as_uint(vc.y)) : NO_HIT_KEY;
+                const unsigned long long k3 = valid3 ? (((unsigned long long) __float_as_uint(dist3) << 32) | __float_as_uint(wc.y)) : NO_HIT_KEY;
+                best_key = min_u64(min_u64(best_key, min_u64(k0, k1)), min_u64(k2, k3));
+                if (sp != bottom) { sp -= LANE_RAYS; ref = *sp; } else ref = NONE;
+            }
+        } else {
+            RVB_MARK("done");
+            if (ref == NONE) {
+                const uint32_t tri = (uint32_t) best_key;
+                ref = IDLE;
+                if (tri != NONE) {                                           // (else: the ray escaped, kernel.cpp:372-375)
+                    const float t = __uint_as_float((uint32_t) (best_key >> 32));
+                    // PathJob::done with one lane: the same operations on the same operands
+                    const float4 * shade = reinterpret_cast<const float4 *>(a.scene.shade + tri);
+                    const float4 sh = shade[0], sk = shade[1];
+                    const v3 normal = mk3(sh.x, sh.y, sh.z);
+                    const uint32_t surface = __float_as_uint(sh.w);
+                    float4 s_lo, s_hi;
+                    if (SURF_LDS) { s_lo = lds_load4(surf_lds, 4 * surface); s_hi = lds_load4(surf_lds, 4 * surface + 1); }
+                    else { const float4 * row = reinterpret_cast<const float4 *>(a.scene.surfaces + surface); s_lo = row[0]; s_hi = row[1]; }
+                    const v3 p = o + d * t;                                  // kernel.cpp:459
+                    const float new_dist = distance + t;                     // kernel.cpp:460
+                    vol_lo = make_float4(-vol_lo.x * s_lo.x, -vol_lo.y * s_lo.y, -vol_lo.z * s_lo.z, -vol_lo.w * s_lo.w);   // kernel.cpp:461
+                    vol_hi = make_float4(-vol_hi.x * s_hi.x, -vol_hi.y * s_hi.y, -vol_hi.z * s_hi.z, -vol_hi.w * s_hi.w);
+                    const float diff = fabsf(dot3(normal, d));               // kernel.cpp:478
+                    const float threshold = unit ? fmaf(sk.z, t, sk.y) : __builtin_inff();      // own-plane skip (bvh.h)
+                    skip = diff > threshold ? __float_as_uint(sk.x) : RVB_BVH_EMPTY;
+                    const uint64_t record = (uint64_t) (uint32_t) ray * a.nreflections + index;
+                    float4 * rec = reinterpret_cast<float4 *>(a.impulses + record);
+                    store_stream(rec + 0, vol_lo);
+                    store_stream(rec + 1, vol_hi);
+                    store_stream(rec + 2, make_float4(p.x, p.y, p.z, diff));
+                    store_stream(rec + 3, make_float4(new_dist, threshold, __uint_as_float(tri), __uint_as_float(pair_tag)));
+                    if (index < RVB_NUM_IMAGE_SOURCE - 1)
+                        a.early[(uint32_t) ray * (RVB_NUM_IMAGE_SOURCE - 1) + index] = tri;
+                    if (a.sort_keys16) {                                     // (wave-uniform) grouping keys leave in 64-byte runs
+                        const uint32_t at = index & (RVB_KEY_RUN - 1u);
+                        key_row[at] = (uint16_t) (__float_as_uint(sk.w) >> a.key_shift);
+                        if (at == RVB_KEY_RUN - 1u) {
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the row's 16-bit stores before its 16-byte loads
+                            const uint4 * src = reinterpret_cast<const uint4 *>(key_row);
+                            uint4 * dst = reinterpret_cast<uint4 *>(a.sort_keys16 + (record - at));
+                            dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+                        }
+                    } else if (a.sort_keys) {
+                        a.sort_keys[record] = __float_as_uint(sk.w);
+                    }
+                    d = reflect3(normal, d);                                 // kernel.cpp:492-499
+                    o = p;
+                    distance = new_dist;
+                    ++index;
+                    if (index < a.nreflections) RVB_RESET_QUERY()
+                }
+            }
+        }
+        RVB_MARK("loop_end");
+    }
+#undef RVB_RESET_QUERY
+    // an escaped ray leaves its remaining slots zero-filled and their grouping keys "no record" (finish_escaped_ray)
+    if (index < a.nreflections) {
+        const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (uint32_t i = index; i < a.nreflections; ++i) {
+            float4 * rec = reinterpret_cast<float4 *>(a.impulses + ((uint64_t) (uint32_t) ray * a.nreflections + i));
+            store_stream(rec + 0, zero); store_stream(rec + 1, zero); store_stream(rec + 2, zero); store_stream(rec + 3, zero);
+            if (a.sort_keys)
+                a.sort_keys[(uint64_t) (uint32_t) ray * a.nreflections + i] = NONE;
+        }
+        if (a.sort_keys16) {
+            uint32_t i = index;
+            const uint32_t at = i & (RVB_KEY_RUN - 1u);
+            const uint4 none = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+            if (at) {
+                for (uint32_t k = at; k < RVB_KEY_RUN; ++k) key_row[k] = 0xFFFFu;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                const uint4 * src = reinterpret_cast<const uint4 *>(key_row);
+                uint4 * dst = reinterpret_cast<uint4 *>(a.sort_keys16 + ((uint64_t) (uint32_t) ray * a.nreflections + (i - at)));
+                dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+                i += RVB_KEY_RUN - at;
+            }
+            for (; i < a.nreflections; i += RVB_KEY_RUN) {
+                uint4 * dst = reinterpret_cast<uint4 *>(a.sort_keys16 + ((uint64_t) (uint32_t) ray * a.nreflections + i));
+                dst[0] = none; dst[1] = none; dst[2] = none; dst[3] = none;
+            }
+        }
+    }
+    atomicAdd(a.executed, (unsigned long long) index);
+}
+
+template <bool SURF_LDS>
+__global__ __launch_bounds__(WAVE, RVB_LANE_WAVES) void path_lane_group_kernel(TraceGroup g)
+{
+    uint32_t which = 0;
+    for (uint32_t k = 1; k < g.count; ++k)
+        which += blockIdx.x >= g.first_block[k] ? 1u : 0u;
+    path_lane_body<SURF_LDS>(g.trace[which], blockIdx.x - g.first_block[which]);
 }
 
 // reference kernel.cpp:243-265 (add_image) for a known-valid slot
@@ -1545,11 +1769,11 @@ __global__ __launch_bounds__(WAVE, RVB_SHADOW_PAIR_WAVES) void shadow_pair_kerne
 
 }  // namespace
 
-// LDS of a quad kernel's single-wave workgroup: the traversal stack, then (optionally) the surface table
-static size_t quad_kernel_lds_bytes(const TraceArgs & a)
+// LDS of a quad kernel's single-wave workgroup: the traversal stack, then (optionally) the surface table, then — path kernel only — the key runs
+static size_t quad_kernel_lds_bytes(const TraceArgs & a, bool key_runs = false)
 {
     return a.stack_entries * QUADS_PER_BLOCK * sizeof(uint32_t) + (size_t) a.lds_surfaces * sizeof(rvb_surface) + RVB_LDS_NODES * 64u
-           + (a.sort_keys16 ? QUADS_PER_BLOCK * RVB_KEY_RUN * sizeof(uint16_t) : 0u);
+           + (key_runs && a.sort_keys16 ? QUADS_PER_BLOCK * RVB_KEY_RUN * sizeof(uint16_t) : 0u);
 }
 
 // LDS of the two-lane path kernel's single-wave workgroup: stack, surface table, (experiment: top nodes), the lanes' cold words
@@ -1559,15 +1783,23 @@ static size_t rvb_pair_lds_bytes(const TraceArgs & a)
            + (RVB_PAIR_COLD ? 5u * WAVE * sizeof(float) : 0u) + (a.sort_keys16 ? PAIRS_PER_BLOCK * RVB_KEY_RUN * sizeof(uint16_t) : 0u);
 }
 
+// LDS of the one-lane path kernel's single-wave workgroup: a stack column per lane (one slack row), surface table, a key run per lane
+static size_t rvb_lane_lds_bytes(const TraceArgs & a)
+{
+    return (a.stack_entries + 1u) * LANE_RAYS * sizeof(uint32_t) + (size_t) a.lds_surfaces * sizeof(rvb_surface)
+           + (a.sort_keys16 ? LANE_RAYS * RVB_KEY_RUN * sizeof(uint16_t) : 0u);
+}
+
 uint32_t rvb_lds_surfaces(uint32_t stack_entries, uint64_t nsurfaces)
 {
-    // 8 waves/SIMD = 32 single-wave workgroups per CU must still fit in the CU's 160 KiB of LDS
+    // 8 waves/SIMD = 32 single-wave workgroups per CU must still fit in the CU's 160 KiB of LDS: stack + key runs + surface table
     static const bool off = getenv("RVB_LDS_SURFACES") && getenv("RVB_LDS_SURFACES")[0] == '0';
     const size_t budget = (160u * 1024u) / 32u;
-    const size_t stack = (size_t) stack_entries * QUADS_PER_BLOCK * sizeof(uint32_t);
-    // ... and the two-lane kernels (twice the stack per workgroup) want 5 waves/SIMD = 20 workgroups per CU
+    const size_t stack = (size_t) stack_entries * QUADS_PER_BLOCK * sizeof(uint32_t) + QUADS_PER_BLOCK * RVB_KEY_RUN * sizeof(uint16_t);
+    // ... and the two-lane kernels (twice the stack and key runs per workgroup, the cold words) want 5 waves/SIMD = 20 workgroups per CU
     const size_t pair_budget = (160u * 1024u) / 20u;
-    const size_t pair_stack = (size_t) stack_entries * PAIRS_PER_BLOCK * sizeof(uint32_t);
+    const size_t pair_stack = (size_t) stack_entries * PAIRS_PER_BLOCK * sizeof(uint32_t) + PAIRS_PER_BLOCK * RVB_KEY_RUN * sizeof(uint16_t)
+                              + (RVB_PAIR_COLD ? 5u * WAVE * sizeof(float) : 0u);
     if (off || nsurfaces == 0 || stack + nsurfaces * sizeof(rvb_surface) > budget || pair_stack + nsurfaces * sizeof(rvb_surface) > pair_budget)
         return 0;
     return (uint32_t) nsurfaces;
@@ -1581,14 +1813,19 @@ uint32_t rvb_lds_surfaces(uint32_t stack_entries, uint64_t nsurfaces)
 uint32_t rvb_path_lanes_for(uint64_t nrays, uint32_t concurrent)
 {
     static const int forced = getenv("RVB_PATH_LANES") ? atoi(getenv("RVB_PATH_LANES")) : 0;     // diagnostic override
-    if (forced == 2 || forced == 4) return (uint32_t) forced;
-    return nrays * (concurrent ? concurrent : 1u) >= 6ull * 1024ull * PAIRS_PER_BLOCK ? 2u : 4u;
+    if (forced == 1 || forced == 2 || forced == 4) return (uint32_t) forced;
+    // one lane per ray (path_lane_group_kernel) once the rays in flight give every SIMD RVB_LANE_MIN_WAVES waves of 64 rays: below
+    // that its launch is bound by the latency of one wave's chain of (longer) steps, above it by how few instructions a ray costs
+    static const uint64_t lane_min_waves = getenv("RVB_LANE_MIN_WAVES") ? strtoull(getenv("RVB_LANE_MIN_WAVES"), nullptr, 10) : 0;
+    const uint64_t in_flight = nrays * (concurrent ? concurrent : 1u);
+    if (lane_min_waves && in_flight >= lane_min_waves * 1024ull * LANE_RAYS) return 1u;
+    return in_flight >= 6ull * 1024ull * PAIRS_PER_BLOCK ? 2u : 4u;
 }
 
 void rvb_launch_path(const TraceArgs & a, hipStream_t s)
 {
     if (a.nrays == 0) return;
-    if (a.path_lanes == 2) {
+    if (a.path_lanes <= 2) {
         // one trace through the group kernel: the form that takes its arguments from the group block needs 80 registers and no scratch
         // (six waves per SIMD); a kernel of its own with TraceArgs by value came out at 86 once the key runs were added
         rvb_launch_path_group(&a, 1, s);
@@ -1597,29 +1834,36 @@ void rvb_launch_path(const TraceArgs & a, hipStream_t s)
     const unsigned blocks = (unsigned) ((a.nrays + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK);
     const bool seven = a.nrays <= 7ull * 1024ull * QUADS_PER_BLOCK;      // fits in seven waves per SIMD: the 72-register build
     if (a.lds_surfaces) {
-        if (seven) hipLaunchKernelGGL((path_kernel<true, 7>), dim3(blocks), dim3(WAVE), quad_kernel_lds_bytes(a), s, a);
-        else hipLaunchKernelGGL((path_kernel<true, 8>), dim3(blocks), dim3(WAVE), quad_kernel_lds_bytes(a), s, a);
+        if (seven) hipLaunchKernelGGL((path_kernel<true, 7>), dim3(blocks), dim3(WAVE), quad_kernel_lds_bytes(a, true), s, a);
+        else hipLaunchKernelGGL((path_kernel<true, 8>), dim3(blocks), dim3(WAVE), quad_kernel_lds_bytes(a, true), s, a);
     } else {
-        if (seven) hipLaunchKernelGGL((path_kernel<false, 7>), dim3(blocks), dim3(WAVE), quad_kernel_lds_bytes(a), s, a);
-        else hipLaunchKernelGGL((path_kernel<false, 8>), dim3(blocks), dim3(WAVE), quad_kernel_lds_bytes(a), s, a);
+        if (seven) hipLaunchKernelGGL((path_kernel<false, 7>), dim3(blocks), dim3(WAVE), quad_kernel_lds_bytes(a, true), s, a);
+        else hipLaunchKernelGGL((path_kernel<false, 8>), dim3(blocks), dim3(WAVE), quad_kernel_lds_bytes(a, true), s, a);
     }
 }
 
+// (the caller checked: every trace has the same lane count, stack depth, number of surfaces staged in LDS and key form)
 void rvb_launch_path_group(const TraceArgs * traces, uint32_t count, hipStream_t s)
 {
     TraceGroup g;
     g.count = count;
+    const TraceArgs & a = traces[0];
+    const uint32_t rays_per_block = a.path_lanes == 1 ? LANE_RAYS : PAIRS_PER_BLOCK;
     uint32_t blocks = 0;
     for (uint32_t k = 0; k < count; ++k) {
         g.first_block[k] = blocks;
         g.trace[k] = traces[k];
-        blocks += (uint32_t) ((traces[k].nrays + PAIRS_PER_BLOCK - 1) / PAIRS_PER_BLOCK);
+        blocks += (uint32_t) ((traces[k].nrays + rays_per_block - 1) / rays_per_block);
     }
     for (uint32_t k = count; k <= RVB_MAX_GROUP; ++k) g.first_block[k] = blocks;
     for (uint32_t k = count; k < RVB_MAX_GROUP; ++k) g.trace[k] = traces[0];
-    // (the caller checked: every trace has the same stack depth and the same number of surfaces staged in LDS)
-    const TraceArgs & a = traces[0];
-    const size_t lds = rvb_pair_lds_bytes(a);
+    size_t lds = 0;                          // (the largest of the traces', should a caller ever group traces whose layouts differ in size)
+    for (uint32_t k = 0; k < count; ++k) lds = std::max(lds, a.path_lanes == 1 ? rvb_lane_lds_bytes(traces[k]) : rvb_pair_lds_bytes(traces[k]));
+    if (a.path_lanes == 1) {
+        if (a.lds_surfaces) hipLaunchKernelGGL(path_lane_group_kernel<true>, dim3(blocks), dim3(WAVE), lds, s, g);
+        else hipLaunchKernelGGL(path_lane_group_kernel<false>, dim3(blocks), dim3(WAVE), lds, s, g);
+        return;
+    }
     if (a.lds_surfaces) hipLaunchKernelGGL(path_pair_group_kernel<true>, dim3(blocks), dim3(WAVE), lds, s, g);
     else hipLaunchKernelGGL(path_pair_group_kernel<false>, dim3(blocks), dim3(WAVE), lds, s, g);
 }

@@ -20,14 +20,17 @@ pytestmark = pytest.mark.gpu
 TRACE_CASES = ["trace_large_square", "trace_echo_tunnel", "trace_random_pillars", "trace_vault"]
 
 
-@pytest.fixture(scope="module", params=["four_lanes_per_ray", "two_lanes_per_ray"])
+@pytest.fixture(scope="module", params=["four_lanes_per_ray", "two_lanes_per_ray", "one_lane_per_ray"])
 def ctx(request):
-    """Every test of this module runs with both path kernels: the quad kernel (what a small launch gets) and the pair kernel
-    (forced here by announcing many concurrent traces, rvb_set_concurrent_traces)."""
+    """Every test of this module runs with all three path kernels: the quad kernel (what a small launch gets), the pair kernel
+    (forced here by announcing many concurrent traces, rvb_set_concurrent_traces) and the one-lane kernel of round 4
+    (rvb_set_path_lanes)."""
     from parallel_reverb_raytracer_amd import capi
     c = capi.Context(0)          # raises when librvb_hip.so or the GPU is missing: no fallback
     if request.param == "two_lanes_per_ray":
         c.set_concurrent_traces(1 << 20)
+    if request.param == "one_lane_per_ray":
+        c.set_path_lanes(1)
     yield c
     c.close()
 
