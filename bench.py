@@ -67,6 +67,8 @@ def parse():
                    "to one GPU; their binning stages run one after the other) instead of all-reducing their own serial sums")
     p.add_argument("--no-host-copy", action="store_true", help="leave the finished histograms in HBM (the round-1/2 metric; diagnostic)")
     p.add_argument("--master-port", type=int, default=0, help="rendezvous port when bench.py starts its own ranks (0: a free one)")
+    p.add_argument("--native", action="store_true", help="one GPU: the timed region is driven by the pipeline behind the C-ABI (rvb_pipeline_*, "
+                   "csrc/pipeline.hip: what a C++ caller gets) instead of distributed.IrPipeline; without the flag it is reported beside the line as native_pipeline")
     p.add_argument("--contexts", type=int, default=4, help="contexts per GPU that take turns (4: the traces of IRs i+2, i+3 are enqueued "
                    "together, beside the grouping / binning / host stages of IRs i, i+1; 2: plain alternation; 1: strictly one IR at a time)")
     return p.parse_args()
@@ -99,7 +101,8 @@ def cpu_baseline(scene, mic, src, nrefl, target_seconds):
             break
         rate = done / spent
         rays = int(max(16 * cores, min(8192 - done, rate * (target_seconds - spent) * 1.1)))
-    what = ("the reference's kernel `raytrace` (rayverb/kernel.cpp) compiled for the host" if kind == "reference"
+    what = ("the TEXT of the reference's kernel `raytrace` (rayverb/kernel.cpp) compiled for the host with the 13 OpenCL built-ins of "
+            "oracle/ref/ref_builtins.cl (this repository's definitions)" if kind == "reference"
             else "this repo's C restatement of the reference kernel")
     return {"value": done * nrefl / spent, "unit": "ray-bounces/s", "cores": cores, "kind": kind,
             "sample": "%s, first %d rays x %d bounces of the same ray set and scene, brute force over all triangles as the reference does, %.1f s"
@@ -237,25 +240,33 @@ def main():
     # context's export stream beside the next IRs' kernels); the timed region ends when the last copy has landed (fence() waits for
     # every stream of the device).
     to_host = not args.no_host_copy
-    host_ring, in_flight = [], {}
+    host_ring, in_flight, slot_of = [], {}, {}
 
     def host_out(shape):
+        """A pinned buffer of the ring for the IR being generated.  The ring slot is tied to the IR through the buffer itself (slot_of:
+        address -> slot; keep() files the device histogram and its tracer under that slot), not through shared 'last slot' state: the
+        pipeline calls this for every IR of a group before it hands any of them to keep()."""
         if not host_ring or tuple(host_ring[0].shape) != tuple(shape):
             torch.cuda.synchronize()
+            for c in contexts:
+                c.synchronize_exports()
             host_ring[:] = [torch.empty(shape, dtype=torch.float32, pin_memory=True) for _ in range(2 * max(1, args.contexts))]
             in_flight.clear()
+            slot_of.clear()
+            slot_of.update({h.data_ptr(): i for i, h in enumerate(host_ring)})
             state["slot"] = 0
         slot = state["slot"] % len(host_ring)
         state["slot"] += 1
         if slot in in_flight:                               # the copy that last used this buffer (2 x contexts IRs ago): done long since
             in_flight.pop(slot)[1].synchronize_exports()
-        state["last_slot"] = slot
         return host_ring[slot]
 
     def keep(hist, info, tracer):
         state.update(hist=hist, nbins=info["nbins"], images=info["images"], predelay=info["predelay"], host=info.get("host"))
         if info.get("host") is not None:
-            in_flight[state["last_slot"]] = (hist, tracer)  # the device histogram stays alive until its copy has left
+            # the device histogram stays alive (and its ring slot taken) until its export has been waited for
+            in_flight[slot_of[info["host"].data_ptr()]] = (hist, tracer)
+        state["kept"] = state.get("kept", 0) + 1
 
     def fence():
         for c in contexts:
@@ -280,14 +291,14 @@ def main():
     # untimed: every context allocates its buffers, then a few IRs strictly alone for the per-kernel "solo" durations and the
     # latency of one IR — to the histogram in HBM (ir_gen_wall_ms) and on to pinned host memory (ir_gen_to_host_ms)
     for c in contexts:
-        distributed.generate_ir(c, *trace_args, **ir_kwargs(None))
+        keep(*distributed.generate_ir(c, *trace_args, **ir_kwargs(None)), c)      # (the histogram stays alive until its export has landed)
     fence()
     for c in contexts:
         c.set_concurrent_traces(1)                  # alone on the GPU: what a caller with one IR gets (the pipeline announced its group)
     solo_irs = 4
     t0 = time.perf_counter()
     for _ in range(solo_irs):
-        h, _ = distributed.generate_ir(ctx, *trace_args, **ir_kwargs(solo_ms))
+        keep(*distributed.generate_ir(ctx, *trace_args, **ir_kwargs(solo_ms)), ctx)
         ctx.synchronize()
         ctx.synchronize_exports()
     solo_latency_ms = (time.perf_counter() - t0) * 1e3 / solo_irs
@@ -307,14 +318,53 @@ def main():
         # the path kernel the pipeline's contexts use (two lanes per ray when two traces are in flight), also alone on the GPU
         pair_solo = {}
         for _ in range(2):
-            distributed.generate_ir(ctx, *trace_args, **ir_kwargs(pair_solo))
+            keep(*distributed.generate_ir(ctx, *trace_args, **ir_kwargs(pair_solo)), ctx)
             ctx.synchronize()
         for k, v in pair_solo.items():
             if k not in solo_ms:
                 solo_ms[k] = v
 
-    pipeline.run(args.warmup, trace_args, ir_kwargs(None), keep)
-    elapsed = timed(args.steps, ir_kwargs(kernel_ms))
+    def timed_native(steps, warmup, native_mode):
+        """The same region through rvb_pipeline_* (csrc/pipeline.hip): jobs submitted a few ahead of the results taken, every histogram
+        in the pipeline's pinned ring when rvb_pipeline_next returns.  Returns (seconds, last histogram as a tensor, info)."""
+        native = capi.Pipeline(contexts)
+        try:
+            native.configure_speakers(speakers_dir, speakers_coeff, nrefl, dtypes.AIR_COEFFICIENTS, sr, True, native_mode)
+
+            def run(count):
+                submitted = taken = 0
+                last = None
+                while taken < count:
+                    while submitted < count and native.pending() < 2 * len(contexts):
+                        native.submit(mic, src)
+                        submitted += 1
+                    last = native.next(copy=False)
+                    taken += 1
+                return last
+            run(warmup)
+            fence()
+            t0 = time.perf_counter()
+            view, info = run(steps)
+            fence()
+            seconds = time.perf_counter() - t0
+            return seconds, torch.from_numpy(view.copy()), info
+        finally:
+            native.close()
+            for c in contexts:
+                c.set_concurrent_traces(pipeline.group_size(len(contexts)))
+
+    native_leg = None
+    if args.native and world == 1 and not grouped:
+        elapsed, native_hist, native_info = timed_native(args.steps, args.warmup, mode)
+        state.update(host=native_hist, hist=native_hist, nbins=native_info["nbins"], images=native_info["images"], predelay=native_info["predelay"])
+        host_ring[:] = []                                   # (the ring check below is the Python pipeline's)
+        # per-kernel elapsed times of the timed region are the Python pipeline's hook: one short pass for the report
+        pipeline.run(4, trace_args, ir_kwargs(kernel_ms), keep)
+        state.update(host=native_hist, hist=native_hist, nbins=native_info["nbins"], images=native_info["images"], predelay=native_info["predelay"])
+        host_ring[:] = []
+    else:
+        pipeline.run(args.warmup, trace_args, ir_kwargs(None), keep)
+        elapsed = timed(args.steps, ir_kwargs(kernel_ms))
 
     ms_per_step = elapsed / args.steps * 1e3
     bounces_per_step = world * rays_per_gpu * nrefl
@@ -328,22 +378,26 @@ def main():
     # Exact mode on one rank: bit for bit (the serial-order sum has one value).  Several ranks add their serial sums with an
     # all-reduce, float atomics have no fixed order: there the bar is the stated tolerance, 1e-5 of each band's largest value.
     timed_hist = (state["host"] if to_host else state["hist"].cpu()).clone()
+    # every buffer of the ring holds one of the region's last 2 x contexts IRs as it landed on the host (the timed IRs are identical jobs)
+    landed = [h.clone() for h in host_ring] if to_host and args.steps >= len(host_ring) else []
     solo_hist, _ = distributed.generate_ir(ctx, *trace_args, **dict(ir_kwargs(None), host_out=None))
     fence()
     solo_host = solo_hist.cpu()
     bit_equal = bool(torch.equal(timed_hist, solo_host))
+    ring_equal = [bool(torch.equal(h, solo_host)) if h.shape == solo_host.shape else False for h in landed]
     band_max = solo_host.double().abs().amax(dim=2, keepdim=True).clamp_min(1e-300)
     worst = float(((timed_hist.double() - solo_host.double()).abs() / band_max).max()) if timed_hist.shape == solo_host.shape else float("inf")
     must_be_equal = args.mode == "exact" and (world == 1 or args.exact_chain)
     timed_check = {"last_timed_histogram_equals_solo_ir": bit_equal, "max_abs_err_over_band_max": worst,
+                   "landed_histograms_checked": len(ring_equal), "landed_histograms_equal_solo_ir": int(sum(ring_equal)),
                    "required": "bit-equal" if must_be_equal else "<= 1e-5 of each band's maximum"}
-    if (must_be_equal and not bit_equal) or worst > 1e-5 or not bool(solo_host.any()):
+    if (must_be_equal and not (bit_equal and all(ring_equal))) or worst > 1e-5 or not bool(solo_host.any()):
         print("bench.py: the timed region's histogram differs from a solo IR: %s" % json.dumps(timed_check), file=sys.stderr)
         sys.exit(4)
     if rank == 0 and os.environ.get("RVB_BENCH_CRC"):       # (checks of the multi-rank modes against one context tracing all the rays)
         import zlib
         print("bench.py: histogram nbins %d crc32 %d" % (solo_host.shape[2], zlib.crc32(solo_host.numpy().tobytes())), file=sys.stderr)
-    del solo_hist, solo_host, timed_hist
+    del solo_hist, solo_host, timed_hist, landed
 
     # the other binning mode through the same timed pipeline, and how far the float-atomic histogram is from the exact one
     other_mode, comparison = None, None
@@ -360,6 +414,14 @@ def main():
             comparison = fast_vs_exact(h_fast, h_exact)
         del h_fast, h_exact
 
+    if not args.no_extras and not args.native and world == 1 and not grouped:
+        # the same region driven through the C-ABI's own pipeline (what a C++ caller gets), its last histogram held against a solo IR
+        n_elapsed, n_hist, n_info = timed_native(args.steps, 4, mode)
+        check, _ = distributed.generate_ir(ctx, *trace_args, **dict(ir_kwargs(None), host_out=None))
+        fence()
+        native_leg = {"what": "rvb_pipeline_* (csrc/pipeline.hip): the schedule behind the C-ABI, driven through ctypes", "ms_per_step": n_elapsed / args.steps * 1e3,
+                      "value": bounces_per_step / (n_elapsed / args.steps), "last_histogram_equals_solo_ir": bool(torch.equal(n_hist, check.cpu()))}
+        del check, n_hist
     attenuate_probe, api_flow = None, None
     if rank == 0 and not args.no_extras:
         # the materialised attenuate kernel (reference kernel `attenuate`, what SpeakerAttenuator::attenuate launches per
@@ -491,7 +553,9 @@ def main():
                                                       if args.mode == "exact" else ": float atomics, order-dependent in the last bits"),
                        "histogram_seconds": state["nbins"] / sr,
                        "sharding": "ray-range shards, replicated scene, one all-reduce(sum) of [2][8][nbins] histograms",
-                       "pipelining": "%d contexts per GPU take turns: traces are enqueued %d at a time, the next group before the current one is finished"
+                       "pipelining": "%d contexts per GPU take turns: traces are enqueued %d at a time, the next group before the current one is finished; "
+                                     "the timed impulse responses are IDENTICAL jobs (same microphone, source and rays every step; jobs that differ — "
+                                     "the 64 pairs of config C5 — run in tests/test_gpu_decomposition.py and tests/cpp/test_pipeline.cpp)"
                                      % (len(contexts), max(1, len(contexts) // 2))},
             "lanes_per_ray": {"path_kernel_in_timed_region": 2 if "path_pair_kernel" in avg else 4,
                               "path_kernel_one_ir_alone": 4 if "path_kernel" in solo else 2, "shadow_kernel": 2 if "shadow_pair_kernel" in solo else 4,
@@ -501,6 +565,9 @@ def main():
             "ir_gen_wall_ms": to_host_latency_ms, "ir_gen_to_host_ms": to_host_latency_ms, "ir_gen_wall_ms_histogram_in_hbm": solo_latency_ms,
             "result_on_host_in_timed_region": to_host, "timed_region_check": timed_check, "contexts_per_gpu": len(contexts),
             "fast_mode" if args.mode == "exact" else "exact_mode": other_mode, "fast_vs_exact": comparison, "api_flow": api_flow,
+            "driver": ("rvb_pipeline_* (csrc/pipeline.hip, the C-ABI's own pipeline, through ctypes)" if args.native and world == 1 and not grouped
+                       else "distributed.IrPipeline (Python over the C-ABI; the N > 1 form with torch.distributed collectives)"),
+            "native_pipeline": native_leg,
             "trace_only_ray_bounces_per_sec": (nrays * nrefl) / (trace_ms * 1e-3) if trace_ms else None,
             "executed_bounces_rank0": int(executed), "nominal_bounces_rank0": nrays * nrefl,
             "kernel_elapsed_ms_timed_region": avg, "kernel_ms": solo, "nbins": state["nbins"], "image_sources": state["images"], "predelay_s": state["predelay"],

@@ -67,8 +67,12 @@ int rvb_synchronize(rvb_ctx * ctx);                     /* wait for the context'
 /* Work submitted to the context after this call starts only after `hip_event` (a hipEvent_t recorded on another stream,
  * e.g. the one a caller-owned buffer was zeroed on) has completed.  No host synchronisation. */
 int rvb_wait_for_event(rvb_ctx * ctx, void * hip_event);
-/* Name ("gfx950"), compute-unit count and HBM bytes of the bound device. */
+/* Records `hip_event` (a hipEvent_t of the caller's) behind the work submitted to the context so far: the counterpart of rvb_wait_for_event
+ * for a caller that hands a buffer the context has written to a stream of its own (e.g. a histogram block to the next device). */
+int rvb_record_event(rvb_ctx * ctx, void * hip_event);
+/* Name ("gfx950"), compute-unit count and HBM bytes of the bound device; its HIP device index. */
 int rvb_device_info(rvb_ctx * ctx, char * arch, uint64_t arch_capacity, int * compute_units, uint64_t * hbm_bytes);
+int rvb_device_index(rvb_ctx * ctx, int * device);
 
 /* ---- scene: replaces the geometry half of Raytracer::Raytracer (rayverb.cpp:242-293) --------
  * Copies triangles / vertices / surfaces, builds the BVH on the host and uploads everything.
@@ -196,6 +200,27 @@ int rvb_ir_time_range(rvb_ctx * ctx, float * min_nonzero_time, float * max_time)
 uint64_t rvb_ir_bins(float max_time, float predelay, float sample_rate);
 int rvb_ir_accumulate(rvb_ctx * ctx, float predelay, float sample_rate, uint64_t nbins, int mode,
                       void * d_histogram);
+/* rvb_ir_accumulate as above, and the finished [nchannels][8][nbins] histogram on its way to
+ * pinned_dst (pinned host memory of the same size: rvb_host_alloc, hipHostMalloc, torch's pin_memory) on the context's export stream:
+ * rvb_synchronize_exports waits for it, rvb_synchronize does not, the context's next trace does not either.  In exact mode with the
+ * exact mode the last kernel of the stage can fold the histogram in `slices` bin ranges, every range leaving as soon as it is final
+ * (the copy of all but the last range then runs beside the folding of the later ones); 0 = the default, ONE piece (= rvb_ir_accumulate +
+ * rvb_copy_to_pinned_host_async): at workload C2 the ranges buy nothing — 54 MB need 1.1 ms of the link whenever they start, the fold
+ * they could hide behind is 0.27 ms (profiles/r04_export_slices_n1.txt).  The float-atomic mode always copies the finished histogram
+ * in one piece.  d_histogram must stay untouched until
+ * the export has been waited for.  Reference counterpart: the blocking cl::copy of every result (rayverb.cpp:645-651, :678, :816). */
+int rvb_ir_accumulate_export(rvb_ctx * ctx, float predelay, float sample_rate, uint64_t nbins, int mode,
+                             void * d_histogram, void * pinned_dst, uint32_t slices);
+/* RVB_IR_EXACT in two steps, for callers that hand the histogram on BLOCK BY BLOCK (the systolic chain over devices of csrc/multi.hip,
+ * distributed.generate_ir(chain_exact=True)):
+ *   rvb_ir_exact_prepare   everything that does not depend on what the histogram holds — bin keys, the radix sort, where each bin's run
+ *                          starts and ends; every device of a chain does this as soon as its trace is done;
+ *   rvb_ir_exact_fold      bins [bin_begin, bin_end): each bin's impulses added in impulse order on top of what d_histogram holds
+ *                          (rayverb.cpp:67-74) — folding all bins once equals rvb_ir_accumulate(..., RVB_IR_EXACT, ...).
+ * The prepared list lives in the context's sort buffers: a call that reuses them (rvb_ir_configure_*, rvb_trace, rvb_flatten*,
+ * rvb_ir_accumulate) voids it and rvb_ir_exact_fold then fails with RVB_ERR_STATE.  Both are asynchronous on the context's stream. */
+int rvb_ir_exact_prepare(rvb_ctx * ctx, float predelay, float sample_rate, uint64_t nbins);
+int rvb_ir_exact_fold(rvb_ctx * ctx, uint64_t nbins, uint64_t bin_begin, uint64_t bin_end, void * d_histogram);
 /* Convenience for one GPU: steps 1-3 done, histogram copied to host memory [nchannels][8][*nbins]. */
 int rvb_ir_download(rvb_ctx * ctx, int trim_predelay, float sample_rate, int mode,
                     float * out, uint64_t capacity_bins, uint64_t * nbins);
@@ -245,6 +270,12 @@ const char * rvb_multi_last_error(const rvb_multi * m);
 int rvb_multi_devices(const rvb_multi * m);
 /* The context of device slot `index` and the ray range it traced (e.g. to run independent (source, listener) pairs per device). */
 int rvb_multi_context(rvb_multi * m, int index, rvb_ctx ** ctx, uint64_t * first_ray, uint64_t * nrays);
+/* RVB_IR_EXACT over several devices is a SYSTOLIC chain: the [nchannels][8][nbins] histogram travels in `blocks` bin-range blocks
+ * (default 8), device g folds block k while device g + 1 folds block k - 1 — (D + blocks - 1) / blocks folds and hops instead of D.
+ * Any block count gives the same bytes (tests/test_gpu_multi.py forces 1, 3 and 8).  rvb_multi_peer_links: directed pairs of distinct
+ * devices for which rvb_multi_create could enable peer access (0 on one GPU); without it the runtime stages the hops through the host. */
+int rvb_multi_set_chain_blocks(rvb_multi * m, uint32_t blocks);
+int rvb_multi_peer_links(const rvb_multi * m);
 int rvb_multi_used_rccl(const rvb_multi * m);            /* 1 if the last RVB_IR_FAST histogram was summed by RCCL */
 int rvb_multi_set_scene(rvb_multi * m, const rvb_triangle * triangles, uint64_t ntriangles, const rvb_float3 * vertices, uint64_t nvertices,
                         const rvb_surface * surfaces, uint64_t nsurfaces);
@@ -260,6 +291,45 @@ int rvb_multi_ir_speakers(rvb_multi * m, const float mic[3], const rvb_speaker *
 int rvb_multi_ir_hrtf(rvb_multi * m, const float mic[3], const float * table /* [2][360*180*8] */, const float facing[3], const float up[3],
                       int which, int remove_direct, int trim_predelay, float sample_rate, int mode,
                       float * out, uint64_t capacity_bins, uint64_t * nbins);
+
+/* ---- impulse responses back to back (csrc/pipeline.hip) --------------------------------------------------------------------
+ * What a batch caller of the reference does with cmd/main.cpp:241-298 in a loop — raytrace, attenuate per channel, fixPredelay,
+ * flattenImpulses per impulse response, every stage blocking — as a pipeline over several contexts of ONE GPU.  The contexts are the
+ * caller's and stay the caller's: every one holds the same scene (rvb_set_scene) and the same rays (rvb_set_directions*) before the
+ * pipeline is created, and is not used for anything else while jobs are pending.  Job i runs on context i % count.  Jobs are traced
+ * in groups of `group` contexts with ONE path-kernel launch per group (rvb_trace_group; 0 = count / 2, at most
+ * RVB_PIPELINE_MAX_GROUP), the traces of the group after next go out before the current group is finished, the binning stages of a
+ * group are enqueued together, and every histogram leaves for pinned host memory on its context's export stream, bin range by bin
+ * range (rvb_ir_accumulate_export).  Measured at workload C2 with 4 contexts: the rate bench.py reports.
+ *   rvb_pipeline_configure_*   the attenuation model and the binning of all jobs that follow (no jobs may be pending)
+ *   rvb_pipeline_submit        one impulse response: microphone and source (HRTF: the configured facing / up; _oriented: its own).
+ *                              Never blocks; RVB_ERR_CAPACITY when 4 x count jobs are pending (take results first)
+ *   rvb_pipeline_next          blocks until the OLDEST pending job's [nchannels][8][nbins] histogram is in host memory; the result's
+ *                              `histogram` points into the pipeline's ring of pinned buffers and stays valid until `count` further
+ *                              results have been taken (or the pipeline is destroyed)
+ * Results are those of rvb_trace + rvb_merge_images + rvb_ir_configure_* + rvb_ir_download on one context, bit for bit in
+ * RVB_IR_EXACT (tests/cpp/test_pipeline.cpp).  Not thread-safe. */
+#define RVB_PIPELINE_MAX_GROUP 4
+typedef struct rvb_pipeline rvb_pipeline;
+typedef struct {
+    uint64_t job;                 /* submission number: 0, 1, 2, ... */
+    const float * histogram;      /* pinned host memory, [nchannels][8][nbins] */
+    uint64_t nchannels, nbins;
+    float predelay, max_time;     /* seconds: what fixPredelay subtracted (0 without trim_predelay); the latest arrival */
+    uint64_t nimages;             /* merged image-source impulses that took part */
+} rvb_pipeline_result;
+int rvb_pipeline_create(rvb_pipeline ** out, rvb_ctx ** ctxs, uint64_t count, uint64_t group);
+void rvb_pipeline_destroy(rvb_pipeline * p);
+const char * rvb_pipeline_last_error(const rvb_pipeline * p);
+int rvb_pipeline_configure_speakers(rvb_pipeline * p, const rvb_speaker * speakers, uint64_t nspeakers, int which, int remove_direct,
+                                    int trim_predelay, float sample_rate, int mode, uint64_t nreflections, const float air_coefficient[8]);
+int rvb_pipeline_configure_hrtf(rvb_pipeline * p, const float * table /* [2][360*180*8] */, const float facing[3], const float up[3],
+                                int which, int remove_direct, int trim_predelay, float sample_rate, int mode, uint64_t nreflections,
+                                const float air_coefficient[8]);
+int rvb_pipeline_submit(rvb_pipeline * p, const float mic[3], const float source[3]);
+int rvb_pipeline_submit_oriented(rvb_pipeline * p, const float mic[3], const float source[3], const float facing[3], const float up[3]);
+uint64_t rvb_pipeline_pending(const rvb_pipeline * p);
+int rvb_pipeline_next(rvb_pipeline * p, rvb_pipeline_result * out);
 
 /* ---- measurement hooks (bench.py) ------------------------------------------------------------
  * Durations in milliseconds of the kernels of the last rvb_trace / rvb_ir_accumulate, taken with

@@ -28,13 +28,15 @@ SYMBOLS = [
     "rvb_trace_pairs", "rvb_ir_select_pair",
     "rvb_get_diffuse", "rvb_diffuse_device", "rvb_get_direct", "rvb_get_image_candidates", "rvb_merge_images",
     "rvb_attenuate_speaker", "rvb_attenuate_speaker_device", "rvb_attenuate_hrtf", "rvb_attenuate_hrtf_device", "rvb_flatten",
-    "rvb_ir_configure_speakers", "rvb_ir_configure_hrtf", "rvb_ir_time_range", "rvb_ir_bins", "rvb_ir_accumulate",
+    "rvb_ir_configure_speakers", "rvb_ir_configure_hrtf", "rvb_ir_time_range", "rvb_ir_bins", "rvb_ir_accumulate", "rvb_ir_accumulate_export", "rvb_ir_exact_prepare", "rvb_ir_exact_fold", "rvb_record_event",
     "rvb_ir_download", "rvb_last_timings", "rvb_debug_stamps", "rvb_executed_bounces",
     "rvb_device_alloc", "rvb_device_free", "rvb_copy_to_host", "rvb_copy_to_device", "rvb_fix_predelay_device", "rvb_flatten_device",
     "rvb_host_alloc", "rvb_host_free", "rvb_copy_to_pinned_host_async", "rvb_synchronize_exports",
-    "rvb_multi_create", "rvb_multi_destroy", "rvb_multi_last_error", "rvb_multi_devices", "rvb_multi_context", "rvb_multi_used_rccl",
+    "rvb_multi_create", "rvb_multi_destroy", "rvb_multi_last_error", "rvb_multi_devices", "rvb_multi_context", "rvb_multi_used_rccl", "rvb_multi_set_chain_blocks", "rvb_multi_peer_links",
     "rvb_multi_set_scene", "rvb_multi_set_directions", "rvb_multi_trace", "rvb_multi_get_diffuse", "rvb_multi_get_images",
     "rvb_multi_ir_speakers", "rvb_multi_ir_hrtf",
+    "rvb_device_index", "rvb_pipeline_create", "rvb_pipeline_destroy", "rvb_pipeline_last_error", "rvb_pipeline_configure_speakers",
+    "rvb_pipeline_configure_hrtf", "rvb_pipeline_submit", "rvb_pipeline_submit_oriented", "rvb_pipeline_pending", "rvb_pipeline_next",
 ]
 
 _vp = ctypes.c_void_p
@@ -74,6 +76,12 @@ def load_library():
         lib.rvb_multi_destroy.argtypes = [_vp]
         lib.rvb_multi_last_error.restype = ctypes.c_char_p
         lib.rvb_multi_last_error.argtypes = [_vp]
+        lib.rvb_pipeline_last_error.restype = ctypes.c_char_p
+        lib.rvb_pipeline_last_error.argtypes = [_vp]
+        lib.rvb_pipeline_destroy.restype = None
+        lib.rvb_pipeline_destroy.argtypes = [_vp]
+        lib.rvb_pipeline_pending.restype = _u64
+        lib.rvb_pipeline_pending.argtypes = [_vp]
         _lib = lib
     return _lib
 
@@ -361,6 +369,36 @@ class Context:
         self.ir_accumulate(predelay, sample_rate, nbins, mode, tensor.data_ptr())
         self._keep_event = ready                       # alive until the next call (the wait has been enqueued, not executed)
 
+    def ir_accumulate_export_tensor(self, predelay, sample_rate, nbins, mode, tensor, pinned_host_tensor, slices=0):
+        """ir_accumulate_tensor + export_tensor_to_host in one call (rvb_ir_accumulate_export): in exact mode with the speaker model
+        the histogram leaves for the host bin range by bin range while the later ranges are still being folded."""
+        import torch
+        assert tensor.is_cuda and tensor.is_contiguous() and tensor.numel() == self.nchannels * 8 * nbins
+        assert pinned_host_tensor.is_pinned() and pinned_host_tensor.is_contiguous()
+        assert tensor.numel() * tensor.element_size() == pinned_host_tensor.numel() * pinned_host_tensor.element_size()
+        ready = torch.cuda.Event()
+        ready.record()
+        self._check(self.lib.rvb_wait_for_event(self.handle, _vp(ready.cuda_event)))
+        self._check(self.lib.rvb_ir_accumulate_export(self.handle, ctypes.c_float(predelay), ctypes.c_float(sample_rate), _u64(nbins),
+                                                      ctypes.c_int(mode), _vp(tensor.data_ptr()), _vp(pinned_host_tensor.data_ptr()),
+                                                      ctypes.c_uint32(int(slices))))
+        self._keep_event = ready
+
+    def ir_exact_prepare(self, predelay, sample_rate, nbins):
+        """Exact mode, step 1: keys, sort, run boundaries of this context's impulses (rvb_ir_exact_prepare)."""
+        self._check(self.lib.rvb_ir_exact_prepare(self.handle, ctypes.c_float(predelay), ctypes.c_float(sample_rate), _u64(nbins)))
+
+    def ir_exact_fold_tensor(self, nbins, bin_begin, bin_end, tensor):
+        """Exact mode, step 2: bins [bin_begin, bin_end) folded on top of what the torch CUDA tensor [nchannels][8][nbins] holds; the
+        context's stream first waits (by an event) for what torch's current stream has done to the tensor."""
+        import torch
+        assert tensor.is_cuda and tensor.is_contiguous() and tensor.numel() == self.nchannels * 8 * nbins
+        ready = torch.cuda.Event()
+        ready.record()
+        self._check(self.lib.rvb_wait_for_event(self.handle, _vp(ready.cuda_event)))
+        self._check(self.lib.rvb_ir_exact_fold(self.handle, _u64(nbins), _u64(bin_begin), _u64(bin_end), _vp(tensor.data_ptr())))
+        self._keep_event = ready
+
     def export_tensor_to_host(self, tensor, pinned_host_tensor):
         """Enqueues, behind the binning, the copy of a device tensor (the histogram ir_accumulate_tensor filled) into a PINNED host
         tensor of the same size (rvb_copy_to_pinned_host_async: on the context's export stream); synchronize_exports()
@@ -434,6 +472,13 @@ class MultiContext:
     def used_rccl(self):
         return bool(self.lib.rvb_multi_used_rccl(self.handle))
 
+    def set_chain_blocks(self, blocks):
+        """Bin-range blocks the exact mode's histogram travels in from device to device (rvb_multi_set_chain_blocks; same bytes for any count)."""
+        self._check(self.lib.rvb_multi_set_chain_blocks(self.handle, ctypes.c_uint32(int(blocks))))
+
+    def peer_links(self):
+        return int(self.lib.rvb_multi_peer_links(self.handle))
+
     def get_raw_diffuse(self):
         out = np.zeros(self.nrays * self.nreflections, dtype=IMPULSE)
         self._check(self.lib.rvb_multi_get_diffuse(self.handle, _ptr(out)))
@@ -466,3 +511,73 @@ class MultiContext:
         out = np.zeros((2, 8, nbins.value), dtype=np.float32)
         self._check(self.lib.rvb_multi_ir_hrtf(*args, _ptr(out), _u64(nbins.value), ctypes.byref(nbins)))
         return out
+
+
+class PipelineResult(ctypes.Structure):
+    """rvb_pipeline_result of include/rvb_capi.h."""
+    _fields_ = [("job", ctypes.c_uint64), ("histogram", ctypes.POINTER(ctypes.c_float)), ("nchannels", ctypes.c_uint64), ("nbins", ctypes.c_uint64),
+                ("predelay", ctypes.c_float), ("max_time", ctypes.c_float), ("nimages", ctypes.c_uint64)]
+
+
+class Pipeline:
+    """Impulse responses back to back behind the C-ABI (rvb_pipeline_*, csrc/pipeline.hip): the native form of
+    distributed.IrPipeline — groups of traces in one path-kernel launch, the next groups' traces enqueued ahead, the binning stages of a
+    group enqueued together, histograms exported to a ring of pinned buffers.  `contexts`: capi.Context objects of one GPU with the
+    same scene and rays set."""
+
+    def __init__(self, contexts, group=0):
+        self.lib = load_library()
+        self.contexts = list(contexts)
+        self.handle = _vp()
+        handles = (_vp * len(self.contexts))(*[c.handle for c in self.contexts])
+        rc = self.lib.rvb_pipeline_create(ctypes.byref(self.handle), handles, _u64(len(self.contexts)), _u64(int(group)))
+        if rc:
+            raise RvbError(rc, "rvb_pipeline_create failed")
+
+    def close(self):
+        if self.handle:
+            self.lib.rvb_pipeline_destroy(self.handle)
+            self.handle = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise RvbError(rc, self.lib.rvb_pipeline_last_error(self.handle).decode())
+
+    def configure_speakers(self, directions, coefficients, nreflections, air, sample_rate=44100.0, trim_predelay=True, mode=IR_EXACT,
+                           which=IR_ALL, remove_direct=False):
+        sp = make_speakers(directions, coefficients)
+        self._check(self.lib.rvb_pipeline_configure_speakers(self.handle, _ptr(sp), _u64(sp.shape[0]), ctypes.c_int(which), ctypes.c_int(int(remove_direct)),
+                                                             ctypes.c_int(int(trim_predelay)), ctypes.c_float(sample_rate), ctypes.c_int(mode),
+                                                             _u64(nreflections), _f8(air)))
+
+    def configure_hrtf(self, table, facing, up, nreflections, air, sample_rate=44100.0, trim_predelay=True, mode=IR_EXACT, which=IR_ALL,
+                       remove_direct=False):
+        t = np.ascontiguousarray(table, dtype=np.float32)
+        assert t.size == 2 * 360 * 180 * 8
+        self._check(self.lib.rvb_pipeline_configure_hrtf(self.handle, _ptr(t), _f3(facing), _f3(up), ctypes.c_int(which), ctypes.c_int(int(remove_direct)),
+                                                         ctypes.c_int(int(trim_predelay)), ctypes.c_float(sample_rate), ctypes.c_int(mode),
+                                                         _u64(nreflections), _f8(air)))
+
+    def submit(self, mic, source, facing=None, up=None):
+        if facing is None:
+            self._check(self.lib.rvb_pipeline_submit(self.handle, _f3(mic), _f3(source)))
+        else:
+            self._check(self.lib.rvb_pipeline_submit_oriented(self.handle, _f3(mic), _f3(source), _f3(facing), _f3(up)))
+
+    def pending(self):
+        return int(self.lib.rvb_pipeline_pending(self.handle))
+
+    def next(self, copy=True):
+        """The oldest pending job: (histogram [nchannels][8][nbins] — a copy, or a view of the pipeline's pinned buffer that stays valid
+        until len(contexts) further results have been taken —, info dict)."""
+        res = PipelineResult()
+        self._check(self.lib.rvb_pipeline_next(self.handle, ctypes.byref(res)))
+        view = np.ctypeslib.as_array(res.histogram, shape=(int(res.nchannels), 8, int(res.nbins)))
+        info = {"job": int(res.job), "nbins": int(res.nbins), "predelay": float(res.predelay), "max_time": float(res.max_time), "images": int(res.nimages)}
+        return (view.copy() if copy else view), info

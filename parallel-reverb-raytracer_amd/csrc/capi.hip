@@ -102,6 +102,8 @@ struct rvb_ctx {
     DevBuf own_sort_temp, own_sort_keys, own_sort_values;      // csrc/radix_sort.hip: tile counters, the intermediate (key, value) pair
     uint64_t nimages = 0;
     std::vector<rvb_impulse> images_host;
+    // exact mode in two steps (rvb_ir_exact_prepare / rvb_ir_exact_fold): what the sorted list in keys_b / vals_b / bin_starts was prepared for
+    struct ExactState { bool valid = false; bool hrtf_combined = false; uint64_t nbins = 0, n = 0, ndiffuse = 0, nimages = 0; } exact;
 
     // staged host copies (rvb_copy_to_host / rvb_copy_to_device): per worker thread two pinned bounce buffers and a stream
     struct CopyLane { void * pinned[2] = {nullptr, nullptr}; hipStream_t stream = nullptr; hipEvent_t done[2] = {nullptr, nullptr}; };
@@ -285,6 +287,14 @@ int rvb_wait_for_event(rvb_ctx * ctx, void * hip_event)
     return RVB_OK;
 }
 
+int rvb_record_event(rvb_ctx * ctx, void * hip_event)
+{
+    if (!ctx || !hip_event) return RVB_ERR_INVALID;
+    RVB_BIND(ctx);
+    RVB_HIP(ctx, hipEventRecord(reinterpret_cast<hipEvent_t>(hip_event), ctx->stream));
+    return RVB_OK;
+}
+
 int rvb_synchronize(rvb_ctx * ctx)
 {
     if (!ctx) return RVB_ERR_INVALID;
@@ -302,6 +312,13 @@ int rvb_device_info(rvb_ctx * ctx, char * arch, uint64_t arch_capacity, int * co
     }
     if (compute_units) *compute_units = ctx->compute_units;
     if (hbm_bytes) *hbm_bytes = ctx->hbm_bytes;
+    return RVB_OK;
+}
+
+int rvb_device_index(rvb_ctx * ctx, int * device)
+{
+    if (!ctx || !device) return RVB_ERR_INVALID;
+    *device = ctx->device;
     return RVB_OK;
 }
 
@@ -606,6 +623,7 @@ static int trace_finish(rvb_ctx * ctx, TracePlan & plan, const float * mics)
     ctx->traced = true;
     ctx->small_valid = false;
     ctx->ir_configured = false;
+    ctx->exact.valid = false;
     ctx->npairs = npairs;
     ctx->traced_rays = nrays;
     ctx->ir_pair = 0;
@@ -994,6 +1012,7 @@ static int own_sort(rvb_ctx * ctx, const uint32_t * keys, uint32_t value_base, u
 static int ensure_sort_buffers(rvb_ctx * ctx, uint64_t n)
 {
     if (n * 4 > ctx->keys_a.cap || n * 4 > ctx->vals_a.cap) ctx->flat_host = nullptr;      // the keys of a size query are about to be freed
+    ctx->exact.valid = false;                 // (every caller rewrites the sort buffers)
     RVB_HIP(ctx, ctx->keys_a.ensure(n * 4));
     RVB_HIP(ctx, ctx->keys_b.ensure(n * 4));
     RVB_HIP(ctx, ctx->vals_a.ensure(n * 4));
@@ -1292,6 +1311,7 @@ static int configure_common(rvb_ctx * ctx, int which, const rvb_impulse * images
     if (nimages) RVB_HIP(ctx, hipMemcpyAsync(ctx->images.p, ctx->images_host.data(), nimages * sizeof(rvb_impulse), hipMemcpyHostToDevice, ctx->stream));
     ctx->which = which;
     ctx->ir_configured = true;
+    ctx->exact.valid = false;
     return RVB_OK;
 }
 
@@ -1391,12 +1411,116 @@ uint64_t rvb_ir_bins(float max_time, float predelay, float sample_rate)
     return bins_for(max_time, predelay, sample_rate);
 }
 
-int rvb_ir_accumulate(rvb_ctx * ctx, float predelay, float sample_rate, uint64_t nbins, int mode, void * d_histogram)
+// Exact mode, step 1 (everything that does not depend on what the histogram holds): per-impulse bin keys, the radix sort, where each
+// bin's run starts and ends.  Speaker channels keep the input time (kernel.cpp:530-533) and share ONE sorted list; the two HRTF ears
+// shift the arrival time differently (kernel.cpp:616-622) and are keyed in one pass into ONE list of 2 n entries (bin_keys_hrtf_kernel).
+static int exact_prepare(rvb_ctx * ctx, float predelay, float sample_rate, uint64_t nbins)
+{
+    const AttenuationModel & m = ctx->model;
+    const uint64_t ndiffuse = (ctx->which & RVB_IR_DIFFUSE) ? ctx->nrays * ctx->nreflections : 0;
+    const uint64_t nimages = (ctx->which & RVB_IR_IMAGES) ? ctx->nimages : 0;
+    const uint64_t n = ndiffuse + nimages;
+    if (n >= (1ull << 31)) return fail(ctx, RVB_ERR_CAPACITY, "rvb_ir_accumulate: too many impulses for exact mode");
+    if (nbins >= 0x7FFFFFF0ull) return fail(ctx, RVB_ERR_CAPACITY, "rvb_ir_accumulate: too many bins for exact mode");
+    ctx->flat_host = nullptr;                 // keys_a / vals_a are rewritten below: a pending rvb_flatten size query is void
+    if (m.hrtf) {
+        int rc = ensure_sort_buffers(ctx, 2 * n);
+        if (rc != RVB_OK) return rc;
+        const uint64_t nkeys = 2 * (nbins + 1);
+        const int bits = key_bits_for(nkeys - 1);
+        RVB_HIP(ctx, ctx->bin_starts.ensure(nkeys * 8));       // starts, then ends
+        rvb_launch_bin_keys_hrtf(m, ir_diffuse(ctx), ndiffuse, 0, n, predelay, sample_rate, (uint32_t) nbins,
+                                 ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), ctx->stream);
+        rvb_launch_bin_keys_hrtf(m, ctx->images.as<rvb_impulse>(), nimages, ndiffuse, n, predelay, sample_rate, (uint32_t) nbins,
+                                 ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), ctx->stream);
+        // (explicit values — the two halves carry the same impulse numbers — and always rocPRIM's sort: RVB_SORT=own takes identity values only.
+        // Values derived from the entry's position by a transform iterator instead of an array: 1.52 -> 1.58 ms, and 0.85 -> 0.88 ms for the
+        // one-list speaker form; rocPRIM's first pass reads an array faster than it evaluates an iterator.)
+        rvb_sort_pairs(ctx->sort_temp.p, ctx->sort_temp.cap, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(),
+                       ctx->vals_a.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), 2 * n, bits, ctx->stream);
+        RVB_HIP(ctx, hipMemsetAsync(ctx->bin_starts.p, 0xFF, nkeys * 4, ctx->stream));
+        rvb_launch_bin_starts(ctx->keys_b.as<uint32_t>(), 2 * n, nkeys, ctx->bin_starts.as<uint32_t>(), ctx->bin_starts.as<uint32_t>() + nkeys, ctx->stream);
+    } else {
+        int rc = ensure_sort_buffers(ctx, n);
+        if (rc != RVB_OK) return rc;
+        // keys are bins, nbins itself marks "adds nothing": key_bits_for(nbins) bits cover 0 .. nbins
+        const int bits = key_bits_for(nbins);
+        const uint32_t sentinel = (uint32_t) nbins;
+        RVB_HIP(ctx, ctx->bin_starts.ensure(nbins * 8));          // starts, then ends
+        rvb_launch_bin_keys(m, 0, ir_diffuse(ctx), ndiffuse, 0, predelay, sample_rate, sentinel,
+                            ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), ctx->stream);
+        rvb_launch_bin_keys(m, 0, ctx->images.as<rvb_impulse>(), nimages, ndiffuse, predelay, sample_rate, sentinel,
+                            ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), ctx->stream);
+        if (own_sort_enabled()) {
+            const int rc2 = own_sort(ctx, ctx->keys_a.as<uint32_t>(), 0u, n, 0, bits, ctx->keys_b.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), true);
+            if (rc2 != RVB_OK) return rc2;
+        } else {
+            rvb_sort_pairs(ctx->sort_temp.p, ctx->sort_temp.cap, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(),
+                           ctx->vals_a.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), n, bits, ctx->stream);
+        }
+        RVB_HIP(ctx, hipMemsetAsync(ctx->bin_starts.p, 0xFF, nbins * 4, ctx->stream));
+        rvb_launch_bin_starts(ctx->keys_b.as<uint32_t>(), n, nbins, ctx->bin_starts.as<uint32_t>(), ctx->bin_starts.as<uint32_t>() + nbins, ctx->stream);
+    }
+    RVB_HIP(ctx, hipGetLastError());
+    ctx->exact.valid = true;                  // (ensure_sort_buffers above cleared it)
+    ctx->exact.hrtf_combined = m.hrtf != 0;
+    ctx->exact.nbins = nbins; ctx->exact.n = n; ctx->exact.ndiffuse = ndiffuse; ctx->exact.nimages = nimages;
+    return RVB_OK;
+}
+
+// Exact mode, step 2: bins [b0, b1) — every bin's impulses added in impulse order ON TOP of what the histogram holds (rayverb.cpp:67-74).
+static int exact_fold(rvb_ctx * ctx, uint64_t b0, uint64_t b1, float * hist)
+{
+    const AttenuationModel & m = ctx->model;
+    const rvb_ctx::ExactState & e = ctx->exact;
+    if (!e.valid) return fail(ctx, RVB_ERR_STATE, "rvb_ir_exact_fold: rvb_ir_exact_prepare first (and nothing that reuses the sort buffers in between)");
+    if (b1 > e.nbins) b1 = e.nbins;
+    if (e.hrtf_combined) {
+        const uint64_t nkeys = 2 * (e.nbins + 1);
+        rvb_launch_ordered_sum_hrtf(m, ir_diffuse(ctx), e.ndiffuse, ctx->images.as<rvb_impulse>(), ctx->vals_b.as<uint32_t>(),
+                                    ctx->bin_starts.as<uint32_t>(), ctx->bin_starts.as<uint32_t>() + nkeys, e.nbins, hist, ctx->stream, b0, b1);
+    } else {
+        rvb_launch_ordered_sum(m, 0, m.nchannels, ir_diffuse(ctx), e.ndiffuse, ctx->images.as<rvb_impulse>(), e.nimages, ctx->vals_b.as<uint32_t>(),
+                               ctx->bin_starts.as<uint32_t>(), ctx->bin_starts.as<uint32_t>() + e.nbins, e.n, e.nbins, hist, ctx->stream, b0, b1);
+    }
+    RVB_HIP(ctx, hipGetLastError());
+    return RVB_OK;
+}
+
+// Bins [b0, b1) of every row of the [rows][nbins] histogram leave for pinned host memory on the export stream, behind what the context's
+// stream holds now (rvb_copy_to_pinned_host_async for a bin range: one strided copy).
+static int export_bin_range(rvb_ctx * ctx, float * pinned_dst, const float * hist, uint64_t rows, uint64_t nbins, uint64_t b0, uint64_t b1)
+{
+    if (b1 <= b0) return RVB_OK;
+    RVB_HIP(ctx, hipEventRecord(ctx->export_ready, ctx->stream));
+    RVB_HIP(ctx, hipStreamWaitEvent(ctx->export_stream, ctx->export_ready, 0));
+    if (b0 == 0 && b1 == nbins) {
+        RVB_HIP(ctx, hipMemcpyAsync(pinned_dst, hist, rows * nbins * sizeof(float), hipMemcpyDeviceToHost, ctx->export_stream));
+    } else {
+        static const bool by_rows = getenv("RVB_EXPORT_ROWS") && getenv("RVB_EXPORT_ROWS")[0] == '1';      // measurement: one copy per [channel][band] row
+        if (by_rows) {
+            for (uint64_t r = 0; r < rows; ++r)
+                RVB_HIP(ctx, hipMemcpyAsync(pinned_dst + r * nbins + b0, hist + r * nbins + b0, (b1 - b0) * sizeof(float), hipMemcpyDeviceToHost, ctx->export_stream));
+        } else {
+            RVB_HIP(ctx, hipMemcpy2DAsync(pinned_dst + b0, nbins * sizeof(float), hist + b0, nbins * sizeof(float), (b1 - b0) * sizeof(float), rows,
+                                          hipMemcpyDeviceToHost, ctx->export_stream));
+        }
+    }
+    return RVB_OK;
+}
+
+// rvb_ir_accumulate, and — with pinned_dst — the histogram's way to the host: in exact mode with the speaker model the last kernel of the
+// stage (ordered_sum_kernel: a lane pair per bin) runs bin range by bin range and every range's copy is enqueued behind it, so the link
+// is busy while the later ranges are still being folded; the other forms copy the finished histogram in one piece.
+static int ir_accumulate_impl(rvb_ctx * ctx, float predelay, float sample_rate, uint64_t nbins, int mode, void * d_histogram,
+                              float * pinned_dst, uint32_t slices)
 {
     if (!ctx) return RVB_ERR_INVALID;
     if (!ctx->ir_configured) return fail(ctx, RVB_ERR_STATE, "rvb_ir_accumulate: rvb_ir_configure_* first");
     if (!d_histogram || nbins == 0) return fail(ctx, RVB_ERR_INVALID, "rvb_ir_accumulate: null histogram or no bins");
     RVB_BIND(ctx);
+    if (slices == 0) slices = 1;
+    bool exported = false;
     const AttenuationModel & m = ctx->model;
     const uint64_t ndiffuse = (ctx->which & RVB_IR_DIFFUSE) ? ctx->nrays * ctx->nreflections : 0;
     const uint64_t nimages = (ctx->which & RVB_IR_IMAGES) ? ctx->nimages : 0;
@@ -1414,58 +1538,43 @@ int rvb_ir_accumulate(rvb_ctx * ctx, float predelay, float sample_rate, uint64_t
         rvb_launch_histogram_transpose(ctx->acc.as<float>(), hist, m.nchannels, nbins, ctx->stream);
         ctx->end_timing();
     } else if (mode == RVB_IR_EXACT) {
-        const uint64_t n = ndiffuse + nimages;
-        if (n >= (1ull << 31)) return fail(ctx, RVB_ERR_CAPACITY, "rvb_ir_accumulate: too many impulses for exact mode");
-        if (nbins >= 0x7FFFFFF0ull) return fail(ctx, RVB_ERR_CAPACITY, "rvb_ir_accumulate: too many bins for exact mode");
-        ctx->flat_host = nullptr;                 // keys_a / vals_a are rewritten below: a pending rvb_flatten size query is void
         const char * split_env = getenv("RVB_HRTF_SPLIT_EARS");     // measurement / test switch (read per call): one list per ear, as in round 2
-        const bool split_ears = split_env && split_env[0] == '1';
+        const bool split_ears = m.hrtf && split_env && split_env[0] == '1';
         ctx->begin_timing("exact_mode");
-        if (m.hrtf && !split_ears) {
-            // the two ears shift the arrival time differently (kernel.cpp:616-622): one pass keys every impulse for both ears into ONE
-            // list of 2 n entries, one radix sort orders it, one launch folds both ears (stream_kernels.hip, bin_keys_hrtf_kernel)
-            int rc = ensure_sort_buffers(ctx, 2 * n);
+        if (!split_ears) {
+            // one sorted list (speaker channels share it; the two HRTF ears are keyed into one list of 2 n entries), then the fold —
+            // bin range by bin range when the histogram leaves for the host as it becomes final
+            int rc = exact_prepare(ctx, predelay, sample_rate, nbins);
             if (rc != RVB_OK) return rc;
-            const uint64_t nkeys = 2 * (nbins + 1);
-            const int bits = key_bits_for(nkeys - 1);
-            RVB_HIP(ctx, ctx->bin_starts.ensure(nkeys * 8));       // starts, then ends
-            rvb_launch_bin_keys_hrtf(m, ir_diffuse(ctx), ndiffuse, 0, n, predelay, sample_rate, (uint32_t) nbins,
-                                     ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), ctx->stream);
-            rvb_launch_bin_keys_hrtf(m, ctx->images.as<rvb_impulse>(), nimages, ndiffuse, n, predelay, sample_rate, (uint32_t) nbins,
-                                     ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), ctx->stream);
-            // (explicit values — the two halves carry the same impulse numbers — and always rocPRIM's sort: RVB_SORT=own takes identity values only.
-            // Values derived from the entry's position by a transform iterator instead of an array: 1.52 -> 1.58 ms, and 0.85 -> 0.88 ms for the
-            // one-list speaker form; rocPRIM's first pass reads an array faster than it evaluates an iterator.)
-            rvb_sort_pairs(ctx->sort_temp.p, ctx->sort_temp.cap, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(),
-                           ctx->vals_a.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), 2 * n, bits, ctx->stream);
-            RVB_HIP(ctx, hipMemsetAsync(ctx->bin_starts.p, 0xFF, nkeys * 4, ctx->stream));
-            rvb_launch_bin_starts(ctx->keys_b.as<uint32_t>(), 2 * n, nkeys, ctx->bin_starts.as<uint32_t>(), ctx->bin_starts.as<uint32_t>() + nkeys, ctx->stream);
-            rvb_launch_ordered_sum_hrtf(m, ir_diffuse(ctx), ndiffuse, ctx->images.as<rvb_impulse>(), ctx->vals_b.as<uint32_t>(),
-                                        ctx->bin_starts.as<uint32_t>(), ctx->bin_starts.as<uint32_t>() + nkeys, nbins, hist, ctx->stream);
+            const uint32_t parts = pinned_dst ? slices : 1u;
+            const uint64_t per = ((nbins + parts - 1) / parts + 15) & ~15ull;      // whole 64-byte segments
+            for (uint64_t b0 = 0; b0 < nbins; b0 += per) {
+                const uint64_t b1 = std::min(nbins, b0 + per);
+                rc = exact_fold(ctx, b0, b1, hist);
+                if (rc == RVB_OK && pinned_dst && parts > 1) rc = export_bin_range(ctx, pinned_dst, hist, (uint64_t) m.nchannels * 8, nbins, b0, b1);
+                if (rc != RVB_OK) return rc;
+            }
+            exported = pinned_dst && parts > 1;
         } else {
+            const uint64_t n = ndiffuse + nimages;
+            if (n >= (1ull << 31)) return fail(ctx, RVB_ERR_CAPACITY, "rvb_ir_accumulate: too many impulses for exact mode");
+            if (nbins >= 0x7FFFFFF0ull) return fail(ctx, RVB_ERR_CAPACITY, "rvb_ir_accumulate: too many bins for exact mode");
+            ctx->flat_host = nullptr;
             int rc = ensure_sort_buffers(ctx, n);
             if (rc != RVB_OK) return rc;
-            // keys are bins, nbins itself marks "adds nothing": key_bits_for(nbins) bits cover 0 .. nbins
             const int bits = key_bits_for(nbins);
             const uint32_t sentinel = (uint32_t) nbins;
-            // speaker channels keep the input time (kernel.cpp:530-533): one sorted list serves them all
-            const uint32_t lists = m.hrtf ? m.nchannels : 1u;
             RVB_HIP(ctx, ctx->bin_starts.ensure(nbins * 8));          // starts, then ends
-            for (uint32_t ch = 0; ch < lists; ++ch) {
+            for (uint32_t ch = 0; ch < m.nchannels; ++ch) {           // a list per ear
                 rvb_launch_bin_keys(m, ch, ir_diffuse(ctx), ndiffuse, 0, predelay, sample_rate, sentinel,
                                     ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), ctx->stream);
                 rvb_launch_bin_keys(m, ch, ctx->images.as<rvb_impulse>(), nimages, ndiffuse, predelay, sample_rate, sentinel,
                                     ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), ctx->stream);
-                if (own_sort_enabled()) {
-                    const int rc2 = own_sort(ctx, ctx->keys_a.as<uint32_t>(), 0u, n, 0, bits, ctx->keys_b.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), true);
-                    if (rc2 != RVB_OK) return rc2;
-                } else {
-                    rvb_sort_pairs(ctx->sort_temp.p, ctx->sort_temp.cap, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(),
-                                   ctx->vals_a.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), n, bits, ctx->stream);
-                }
+                rvb_sort_pairs(ctx->sort_temp.p, ctx->sort_temp.cap, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(),
+                               ctx->vals_a.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), n, bits, ctx->stream);
                 RVB_HIP(ctx, hipMemsetAsync(ctx->bin_starts.p, 0xFF, nbins * 4, ctx->stream));
                 rvb_launch_bin_starts(ctx->keys_b.as<uint32_t>(), n, nbins, ctx->bin_starts.as<uint32_t>(), ctx->bin_starts.as<uint32_t>() + nbins, ctx->stream);
-                rvb_launch_ordered_sum(m, ch, m.hrtf ? 1u : m.nchannels, ir_diffuse(ctx), ndiffuse, ctx->images.as<rvb_impulse>(), nimages,
+                rvb_launch_ordered_sum(m, ch, 1u, ir_diffuse(ctx), ndiffuse, ctx->images.as<rvb_impulse>(), nimages,
                                        ctx->vals_b.as<uint32_t>(), ctx->bin_starts.as<uint32_t>(), ctx->bin_starts.as<uint32_t>() + nbins, n, nbins, hist, ctx->stream);
             }
         }
@@ -1474,7 +1583,47 @@ int rvb_ir_accumulate(rvb_ctx * ctx, float predelay, float sample_rate, uint64_t
         return fail(ctx, RVB_ERR_INVALID, "rvb_ir_accumulate: unknown mode");
     }
     RVB_HIP(ctx, hipGetLastError());
+    if (pinned_dst && !exported) return export_bin_range(ctx, pinned_dst, hist, (uint64_t) m.nchannels * 8, nbins, 0, nbins);
     return RVB_OK;
+}
+
+int rvb_ir_accumulate(rvb_ctx * ctx, float predelay, float sample_rate, uint64_t nbins, int mode, void * d_histogram)
+{
+    return ir_accumulate_impl(ctx, predelay, sample_rate, nbins, mode, d_histogram, nullptr, 1);
+}
+
+int rvb_ir_accumulate_export(rvb_ctx * ctx, float predelay, float sample_rate, uint64_t nbins, int mode, void * d_histogram,
+                             void * pinned_dst, uint32_t slices)
+{
+    if (ctx && !pinned_dst) return fail(ctx, RVB_ERR_INVALID, "rvb_ir_accumulate_export: null destination");
+    static const uint32_t env_slices = getenv("RVB_EXPORT_SLICES") ? (uint32_t) atoi(getenv("RVB_EXPORT_SLICES")) : 0;      // measurements
+    // Default: ONE piece.  Measured at workload C2 (profiles/r04_export_slices_n1.txt): 1 / 2 / 4 / 8 bin ranges leave one impulse response
+    // on the host after 6.98 / 7.04 / 7.02 / 7.00 ms (5.88 ms to HBM: the 54 MB need 1.1 ms of the link whenever they start, and the fold they
+    // could overlap is 0.27 ms split into launches that cost what the overlap gains) and the pipeline at 4.82 / 4.81 / 4.80 / 4.96 ms per IR.
+    return ir_accumulate_impl(ctx, predelay, sample_rate, nbins, mode, d_histogram, static_cast<float *>(pinned_dst), env_slices ? env_slices : (slices ? slices : 1u));
+}
+
+int rvb_ir_exact_prepare(rvb_ctx * ctx, float predelay, float sample_rate, uint64_t nbins)
+{
+    if (!ctx) return RVB_ERR_INVALID;
+    if (!ctx->ir_configured) return fail(ctx, RVB_ERR_STATE, "rvb_ir_exact_prepare: rvb_ir_configure_* first");
+    if (nbins == 0) return fail(ctx, RVB_ERR_INVALID, "rvb_ir_exact_prepare: no bins");
+    RVB_BIND(ctx);
+    ctx->reset_timings();
+    ctx->begin_timing("exact_prepare");
+    const int rc = exact_prepare(ctx, predelay, sample_rate, nbins);
+    ctx->end_timing();
+    return rc;
+}
+
+int rvb_ir_exact_fold(rvb_ctx * ctx, uint64_t nbins, uint64_t bin_begin, uint64_t bin_end, void * d_histogram)
+{
+    if (!ctx) return RVB_ERR_INVALID;
+    if (!d_histogram) return fail(ctx, RVB_ERR_INVALID, "rvb_ir_exact_fold: null histogram");
+    if (!ctx->exact.valid || ctx->exact.nbins != nbins) return fail(ctx, RVB_ERR_STATE, "rvb_ir_exact_fold: rvb_ir_exact_prepare with this nbins first");
+    if (bin_begin > bin_end) return fail(ctx, RVB_ERR_INVALID, "rvb_ir_exact_fold: bin range");
+    RVB_BIND(ctx);
+    return exact_fold(ctx, bin_begin, bin_end, static_cast<float *>(d_histogram));
 }
 
 int rvb_ir_download(rvb_ctx * ctx, int trim_predelay, float sample_rate, int mode,

@@ -110,14 +110,14 @@ void rvb_launch_bin_keys(const AttenuationModel & m, uint32_t channel, const rvb
 void rvb_launch_ordered_sum(const AttenuationModel & m, uint32_t first_channel, uint32_t nchannels, const rvb_impulse * diffuse,
                             uint64_t ndiffuse, const rvb_impulse * images, uint64_t nimages,
                             const uint32_t * sorted_values, const uint32_t * starts, const uint32_t * ends, uint64_t n,
-                            uint64_t nbins, float * hist, hipStream_t s);
+                            uint64_t nbins, float * hist, hipStream_t s, uint64_t bin_begin = 0, uint64_t bin_end = ~0ull);   // bins [bin_begin, bin_end) only
 // HRTF model, both ears at once: ONE list of 2 n (key, value) entries — ear e's entry of impulse j at e * n + j, key e * (nbins + 1) + bin
 // (sentinel e * (nbins + 1) + nbins) — and the ordered sum of both ears over its sorted form (starts / ends indexed by that key)
 void rvb_launch_bin_keys_hrtf(const AttenuationModel & m, const rvb_impulse * in, uint64_t count, uint64_t index_base, uint64_t n,
                               float predelay, float sample_rate, uint32_t nbins, uint32_t * keys, uint32_t * values, hipStream_t s);
 void rvb_launch_ordered_sum_hrtf(const AttenuationModel & m, const rvb_impulse * diffuse, uint64_t ndiffuse, const rvb_impulse * images,
                                  const uint32_t * sorted_values, const uint32_t * starts, const uint32_t * ends, uint64_t nbins, float * hist,
-                                 hipStream_t s);
+                                 hipStream_t s, uint64_t bin_begin = 0, uint64_t bin_end = ~0ull);
 // starts[key] / ends[key] = first position of `key` in the sorted list / one past its last (starts[] pre-filled with 0xFFFFFFFF by
 // the caller, nbins entries each; ends[] is only read where starts[] was written)
 void rvb_launch_bin_starts(const uint32_t * sorted_keys, uint64_t n, uint64_t nbins, uint32_t * starts, uint32_t * ends, hipStream_t s);

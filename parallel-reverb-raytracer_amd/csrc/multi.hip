@@ -8,7 +8,10 @@
 //                 continues the same left-to-right float sum with ITS impulses (rvb_ir_accumulate adds on top of what the
 //                 histogram holds), and so on; the merged image sources go last.  Shards are consecutive ray ranges, so the
 //                 chain is the reference's serial order over all rays: bit-identical to one context (and to flattenImpulses).
-//                 The traces — 85 % of the time — still run side by side; only the ~1 ms binning per device is serial.
+//                 The traces — 85 % of the time — still run side by side, and so does every device's keying and sorting
+//                 (rvb_ir_exact_prepare: it does not depend on the incoming histogram).  Only the fold is a chain, and it is
+//                 SYSTOLIC (round 4): the histogram travels in B bin-range blocks, device g folds block k while device g + 1
+//                 folds block k - 1 — (D + B - 1) / B folds and hops instead of D; events, no host waits between devices.
 //   RVB_IR_FAST   every device bins its shard at once (float atomics), then ONE sum over devices: RCCL ncclAllReduce over
 //                 xGMI, loaded from librccl.so at run time; devices that RCCL cannot put in one communicator (the same GPU
 //                 listed twice, as the single-GPU tests do) are summed with peer copies and an add kernel instead.
@@ -79,6 +82,7 @@ struct Shard {
     size_t hist_cap = 0;
     float * peer = nullptr;                   // landing buffer for another device's histogram (fallback sum)
     size_t peer_cap = 0;
+    std::vector<hipEvent_t> arrived, folded;  // exact chain: block k of the histogram has landed on this device / has been folded here
     int rc = RVB_OK;
     std::string error;
 };
@@ -93,6 +97,8 @@ struct rvb_multi {
     std::vector<ncclComm_t> comms;            // one per shard when RCCL serves this device list
     bool rccl_tried = false, rccl_used_last = false;
     unsigned flags = 0;
+    uint32_t chain_blocks = 8;                // bin-range blocks of the exact chain (rvb_multi_set_chain_blocks)
+    int peer_links = 0;                       // directed device pairs with peer access enabled (rvb_multi_create)
     float mic[3] = {0, 0, 0};
     std::vector<rvb_impulse> images;          // merged image sources of the last rvb_multi_ir_* call
 };
@@ -189,9 +195,31 @@ int rvb_multi_create(rvb_multi ** out, const int * devices, int ndevices, unsign
         }
         m->shards.push_back(s);
     }
+    // peer access between every pair of distinct devices (the chain's hops, the fallback sum's gathers): without it the runtime stages a
+    // peer copy through the host.  A refusal is not an error — the copies still work, staged.
+    for (const Shard & a : m->shards)
+        for (const Shard & b : m->shards) {
+            if (a.device == b.device) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, a.device, b.device) != hipSuccess || !can) { (void) hipGetLastError(); continue; }
+            if (hipSetDevice(a.device) != hipSuccess) { (void) hipGetLastError(); continue; }
+            const hipError_t e = hipDeviceEnablePeerAccess(b.device, 0);
+            if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) ++m->peer_links;
+            (void) hipGetLastError();
+        }
     *out = m;
     return RVB_OK;
 }
+
+int rvb_multi_set_chain_blocks(rvb_multi * m, uint32_t blocks)
+{
+    if (!m) return RVB_ERR_INVALID;
+    if (blocks == 0 || blocks > 64) return mfail(m, RVB_ERR_INVALID, "rvb_multi_set_chain_blocks: 1 .. 64");
+    m->chain_blocks = blocks;
+    return RVB_OK;
+}
+
+int rvb_multi_peer_links(const rvb_multi * m) { return m ? m->peer_links : 0; }
 
 void rvb_multi_destroy(rvb_multi * m)
 {
@@ -201,6 +229,8 @@ void rvb_multi_destroy(rvb_multi * m)
     for (Shard & s : m->shards) {
         (void) hipSetDevice(s.device);
         if (s.stream) { (void) hipStreamSynchronize(s.stream); (void) hipStreamDestroy(s.stream); }
+        for (hipEvent_t e : s.arrived) (void) hipEventDestroy(e);
+        for (hipEvent_t e : s.folded) (void) hipEventDestroy(e);
         if (s.hist) (void) hipFree(s.hist);
         if (s.peer) (void) hipFree(s.peer);
         rvb_destroy(s.ctx);
@@ -356,20 +386,58 @@ static int multi_ir(rvb_multi * m, const float mic[3], const rvb_speaker * speak
     m->rccl_used_last = false;
     Shard * result = nullptr;
     if (mode == RVB_IR_EXACT) {
-        // 2a. the chain: shard g continues shard g-1's fold
+        // 2a. the chain, systolic: every device keys and sorts its impulses at once; the histogram then travels in B bin-range blocks
+        // (whole 64-byte segments of every [channel][band] row): device g folds block k behind its arrival from device g - 1, while
+        // device g + 1 folds block k - 1.  Everything is enqueued from this thread in dependency order (an event is recorded before the
+        // wait that names it is enqueued); the host waits once, at the end.
+        const uint64_t rows = (uint64_t) nch * 8;
+        const uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>(m->chain_blocks, (bins + 15) / 16));
+        const uint64_t per = ((bins + blocks - 1) / blocks + 15) & ~15ull;
+        const uint64_t nblocks = (bins + per - 1) / per;
+        for (Shard & s : m->shards) {
+            MHIP(m, hipSetDevice(s.device));
+            while (s.arrived.size() < nblocks) { hipEvent_t e; MHIP(m, hipEventCreateWithFlags(&e, hipEventDisableTiming)); s.arrived.push_back(e); }
+            while (s.folded.size() < nblocks) { hipEvent_t e; MHIP(m, hipEventCreateWithFlags(&e, hipEventDisableTiming)); s.folded.push_back(e); }
+        }
+        const int rc_prep = for_each_shard(m, [&](Shard & s) {
+            if (!(which & RVB_IR_DIFFUSE) || !s.count) return (int) RVB_OK;
+            int r = configure(s.ctx, RVB_IR_DIFFUSE, nullptr, 0);
+            return r != RVB_OK ? r : rvb_ir_exact_prepare(s.ctx, predelay, sample_rate, bins);
+        });
+        if (rc_prep != RVB_OK) return rc_prep;
         for (size_t g = 0; g < m->shards.size(); ++g) {
             Shard & s = m->shards[g];
+            const bool folds = (which & RVB_IR_DIFFUSE) && s.count;
             MHIP(m, hipSetDevice(s.device));
             if (g == 0) MHIP(m, hipMemsetAsync(s.hist, 0, bytes, s.stream));
-            else MHIP(m, hipMemcpyPeerAsync(s.hist, s.device, m->shards[g - 1].hist, m->shards[g - 1].device, bytes, s.stream));
-            MHIP(m, hipStreamSynchronize(s.stream));
-            if ((which & RVB_IR_DIFFUSE) && s.count) {
-                int rc = configure(s.ctx, RVB_IR_DIFFUSE, nullptr, 0);
-                if (rc == RVB_OK) rc = rvb_ir_accumulate(s.ctx, predelay, sample_rate, bins, RVB_IR_EXACT, s.hist);
-                if (rc == RVB_OK) rc = rvb_synchronize(s.ctx);
-                if (rc != RVB_OK) return mfail(m, rc, rvb_last_error(s.ctx));
+            for (uint64_t k = 0; k < nblocks; ++k) {
+                const uint64_t b0 = k * per, b1 = std::min<uint64_t>(bins, b0 + per);
+                if (g > 0) {
+                    Shard & prev = m->shards[g - 1];
+                    MHIP(m, hipStreamWaitEvent(s.stream, prev.folded[k], 0));
+                    if (prev.device == s.device) {
+                        MHIP(m, hipMemcpy2DAsync(s.hist + b0, bins * sizeof(float), prev.hist + b0, bins * sizeof(float), (b1 - b0) * sizeof(float), rows,
+                                                 hipMemcpyDeviceToDevice, s.stream));
+                    } else {
+                        for (uint64_t r = 0; r < rows; ++r)     // (a row's piece of the block is contiguous: one peer copy each)
+                            MHIP(m, hipMemcpyPeerAsync(s.hist + r * bins + b0, s.device, prev.hist + r * bins + b0, prev.device, (b1 - b0) * sizeof(float), s.stream));
+                    }
+                }
+                MHIP(m, hipEventRecord(s.arrived[k], s.stream));
+                if (folds) {
+                    int rc = rvb_wait_for_event(s.ctx, s.arrived[k]);
+                    if (rc == RVB_OK) rc = rvb_ir_exact_fold(s.ctx, bins, b0, b1, s.hist);
+                    if (rc == RVB_OK) rc = rvb_record_event(s.ctx, s.folded[k]);
+                    if (rc != RVB_OK) return mfail(m, rc, rvb_last_error(s.ctx));
+                } else {
+                    MHIP(m, hipEventRecord(s.folded[k], s.stream));          // nothing to add here: the block passes through
+                }
             }
         }
+        // the last device's folds are the end of the chain (a device without impulses only passed blocks on its own stream)
+        MHIP(m, hipSetDevice(last.device));
+        MHIP(m, hipStreamSynchronize(last.stream));
+        { const int rc = rvb_synchronize(last.ctx); if (rc != RVB_OK) return mfail(m, rc, rvb_last_error(last.ctx)); }
         result = &last;
     } else if (mode == RVB_IR_FAST) {
         // 2b. all shards at once, then one sum over the devices

@@ -501,12 +501,14 @@ __global__ __launch_bounds__(64) void ordered_sum_kernel(ModelDev m, uint32_t fi
                                                          uint64_t ndiffuse, const rvb_impulse * __restrict__ images,
                                                          const uint32_t * __restrict__ values,
                                                          const uint32_t * __restrict__ starts, const uint32_t * __restrict__ ends,
-                                                         uint64_t nbins, float * __restrict__ hist)
+                                                         uint64_t nbins, uint64_t bin_begin, uint64_t bin_end, float * __restrict__ hist)
 {
+    // (bins [bin_begin, bin_end) of this launch: the caller may fold the histogram bin range by bin range, each range leaving for
+    // the host as soon as it is final — rvb_ir_accumulate_export)
     const uint64_t t = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t bin = t >> 1;
+    const uint64_t bin = bin_begin + (t >> 1);
     const uint32_t half = (uint32_t) t & 1u;
-    if (bin >= nbins)
+    if (bin >= bin_end)
         return;
     const uint64_t lo = starts[bin];
     if (lo == 0xFFFFFFFFull)
@@ -565,16 +567,16 @@ __global__ __launch_bounds__(64) void ordered_sum_kernel(ModelDev m, uint32_t fi
 __global__ __launch_bounds__(RVB_HRTF_SUM_THREADS) void ordered_sum_hrtf_kernel(ModelDev m, const rvb_impulse * __restrict__ diffuse, uint64_t ndiffuse,
                                                               const rvb_impulse * __restrict__ images, const uint32_t * __restrict__ values,
                                                               const uint32_t * __restrict__ starts, const uint32_t * __restrict__ ends,
-                                                              uint64_t nbins, float * __restrict__ hist)
+                                                              uint64_t nbins, uint64_t bin_begin, uint64_t bin_end, float * __restrict__ hist)
 {
     const uint64_t t = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     // (bin, ear) in bin-major order: a workgroup folds BOTH ears of a run of neighbouring bins.  The two ears' times differ by at
     // most 0.29 ms (13 bins at 44.1 kHz), so the impulses of ear 1's bin b are those of ear 0's bins b-13 .. b+13: gathered by the
     // same workgroup, or its neighbour, at about the same time, the second gather of a record finds it in cache (with all of ear 0's
     // bins first and ear 1's after them every record was fetched from HBM twice).
-    const uint64_t slot = t >> 1;
+    const uint64_t slot = 2 * bin_begin + (t >> 1);          // bins [bin_begin, bin_end) of this launch
     const uint32_t half = (uint32_t) t & 1u;
-    if (slot >= 2 * nbins)
+    if (slot >= 2 * bin_end)
         return;
     const uint32_t ear = (uint32_t) slot & 1u;
     const uint64_t bin = slot >> 1;
@@ -736,24 +738,26 @@ void rvb_launch_bin_keys_hrtf(const AttenuationModel & m, const rvb_impulse * in
 
 void rvb_launch_ordered_sum_hrtf(const AttenuationModel & m, const rvb_impulse * diffuse, uint64_t ndiffuse, const rvb_impulse * images,
                                  const uint32_t * sorted_values, const uint32_t * starts, const uint32_t * ends, uint64_t nbins, float * hist,
-                                 hipStream_t s)
+                                 hipStream_t s, uint64_t bin_begin, uint64_t bin_end)
 {
-    if (nbins == 0) return;
-    hipLaunchKernelGGL(ordered_sum_hrtf_kernel, dim3((unsigned) ((4 * nbins + RVB_HRTF_SUM_THREADS - 1) / RVB_HRTF_SUM_THREADS)), dim3(RVB_HRTF_SUM_THREADS), 0, s, make_model(m), diffuse, ndiffuse,
-                       images, sorted_values, starts, ends, nbins, hist);
+    if (bin_end > nbins) bin_end = nbins;
+    if (nbins == 0 || bin_begin >= bin_end) return;
+    hipLaunchKernelGGL(ordered_sum_hrtf_kernel, dim3((unsigned) ((4 * (bin_end - bin_begin) + RVB_HRTF_SUM_THREADS - 1) / RVB_HRTF_SUM_THREADS)), dim3(RVB_HRTF_SUM_THREADS), 0, s, make_model(m), diffuse, ndiffuse,
+                       images, sorted_values, starts, ends, nbins, bin_begin, bin_end, hist);
 }
 
 void rvb_launch_ordered_sum(const AttenuationModel & m, uint32_t first_channel, uint32_t nchannels, const rvb_impulse * diffuse,
                             uint64_t ndiffuse, const rvb_impulse * images, uint64_t nimages,
                             const uint32_t * sorted_values, const uint32_t * starts, const uint32_t * ends, uint64_t n,
-                            uint64_t nbins, float * hist, hipStream_t s)
+                            uint64_t nbins, float * hist, hipStream_t s, uint64_t bin_begin, uint64_t bin_end)
 {
     (void) nimages;
-    if (nbins == 0 || n == 0) return;
-    const dim3 grid((unsigned) ((2 * nbins + 63) / 64)), block(64);      // two lanes per bin
+    if (bin_end > nbins) bin_end = nbins;
+    if (nbins == 0 || n == 0 || bin_begin >= bin_end) return;
+    const dim3 grid((unsigned) ((2 * (bin_end - bin_begin) + 63) / 64)), block(64);      // two lanes per bin
     const ModelDev md = make_model(m);
 #define RVB_SUM(HRTF, NCH) hipLaunchKernelGGL((ordered_sum_kernel<HRTF, NCH>), grid, block, 0, s, md, first_channel, diffuse, ndiffuse, \
-                                              images, sorted_values, starts, ends, nbins, hist)
+                                              images, sorted_values, starts, ends, nbins, bin_begin, bin_end, hist)
     if (m.hrtf) { RVB_SUM(true, 1); return; }
     switch (nchannels) {                       // speaker channels of one sorted list
     case 1: RVB_SUM(false, 1); break;
@@ -763,7 +767,7 @@ void rvb_launch_ordered_sum(const AttenuationModel & m, uint32_t first_channel, 
     default:                                   // more than four: in groups (64 accumulators per lane would spill)
         for (uint32_t c = 0; c < nchannels; c += 4) {
             const uint32_t k = nchannels - c < 4 ? nchannels - c : 4;
-            rvb_launch_ordered_sum(m, first_channel + c, k, diffuse, ndiffuse, images, nimages, sorted_values, starts, ends, n, nbins, hist, s);
+            rvb_launch_ordered_sum(m, first_channel + c, k, diffuse, ndiffuse, images, nimages, sorted_values, starts, ends, n, nbins, hist, s, bin_begin, bin_end);
         }
     }
 #undef RVB_SUM

@@ -99,6 +99,27 @@ class HrtfModel:
         tracer.ir_configure_hrtf(mic, self.table, self.facing, self.up, which, images)
 
 
+def _p2p_staged(t):
+    """gloo carries point-to-point messages for CPU tensors only: a CUDA block goes through host memory there (RCCL takes it as it is)."""
+    import torch.distributed as dist
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def _send_block(view, dst):
+    import torch.distributed as dist
+    block = view.contiguous()
+    dist.send(block.cpu() if _p2p_staged(block) else block, dst=dst)
+
+
+def _recv_block(view, src):
+    import torch
+    import torch.distributed as dist
+    staged = _p2p_staged(view)
+    block = torch.empty(view.shape, dtype=view.dtype, device="cpu" if staged else view.device)
+    dist.recv(block, src=src)
+    return block.to(view.device) if staged else block
+
+
 def begin_ir(tracer, mic, source, nreflections, air, ray_offset=0):
     """First half of generate_ir: enqueues the trace of the rays already set on `tracer` (asynchronous on a GPU context)."""
     tracer.trace(mic, source, nreflections, air, ray_offset=ray_offset)
@@ -107,7 +128,7 @@ def begin_ir(tracer, mic, source, nreflections, air, ray_offset=0):
 def generate_ir(tracer, mic, source, nreflections, air, speakers_dir=None, speakers_coeff=None, sample_rate=44100.0,
                 trim_predelay=True, mode=capi.IR_FAST, rank=0, world=1, ray_offset=0, device="cpu",
                 which=capi.IR_ALL, remove_direct=False, on_stage=None, begun=False, model=None, collectives=None, defer=False,
-                host_out=None, chain_exact=False):
+                host_out=None, chain_exact=False, chain_blocks=8):
     """One impulse response from the rays already set on `tracer`.  Returns (hist tensor
     [nchannels][8][nbins] — identical on every rank —, info dict).
 
@@ -125,7 +146,9 @@ def generate_ir(tracer, mic, source, nreflections, air, speakers_dir=None, speak
     only up to float re-association — the ranks continue ONE serial sum in ray order: rank r receives the histogram from rank r-1,
     folds its own diffuse impulses on top (rvb_ir_accumulate in exact mode adds to what the histogram holds), hands it to rank r+1;
     the last rank adds the merged image sources (the reference's order: diffuse, then images — rayverb.cpp:708-714) and broadcasts.
-    Bit-identical to one GPU and to flattenImpulses; the binning stages of the ranks run one after the other (the traces do not).
+    Bit-identical to one GPU and to flattenImpulses.  The traces, and every rank's keying and sorting, run side by side; only the
+    fold is a chain, and the histogram travels through it in `chain_blocks` bin-range blocks (rank r folds block k while rank r + 1
+    folds block k - 1: (world + blocks - 1) / blocks folds and hops instead of world).
 
     host_out(shape) -> pinned host tensor: the finished histogram is also copied there (info["host"]) — enqueued behind the binning
     (behind the all-reduce with collectives) on the tracer's export stream, so neither the host nor the tracer's next trace waits for
@@ -184,13 +207,19 @@ def generate_ir(tracer, mic, source, nreflections, air, speakers_dir=None, speak
     nbins = tracer.ir_bins(hi, predelay, sample_rate)
     hist = torch.zeros((model.nchannels, 8, nbins), device=device, dtype=torch.float32)
     chain = collectives and bool(chain_exact) and mode == capi.IR_EXACT and world > 1
-    if contributes and not chain:                        # (the tracer's stream waits for torch's zero fill by an event)
-        tracer.ir_accumulate_tensor(predelay, sample_rate, nbins, mode, hist)
     info = {"nbins": nbins, "predelay": predelay, "images": int(images.shape[0]), "max_time": hi}
     host = host_out(tuple(hist.shape)) if host_out is not None else None
+    # one call for the binning AND the histogram's way to the host where the tracer offers it (rvb_ir_accumulate_export: in exact
+    # mode the bin ranges leave as they become final); otherwise the binning, then the copy behind it in stream order
+    fused_export = host is not None and not collectives and contributes and hasattr(tracer, "ir_accumulate_export_tensor")
+    if contributes and not chain:                        # (the tracer's stream waits for torch's zero fill by an event)
+        if fused_export:
+            tracer.ir_accumulate_export_tensor(predelay, sample_rate, nbins, mode, hist, host)
+        else:
+            tracer.ir_accumulate_tensor(predelay, sample_rate, nbins, mode, hist)
     if host is not None:
         info["host"] = host
-        if not collectives and hasattr(tracer, "export_tensor_to_host"):
+        if not collectives and hasattr(tracer, "export_tensor_to_host") and not fused_export:
             if not contributes:                          # (nothing was enqueued on the tracer's stream: order the copy behind torch's zero fill)
                 tracer.ir_accumulate_wait_for_torch()
             tracer.export_tensor_to_host(hist, host)     # stream order: behind the binning
@@ -199,19 +228,33 @@ def generate_ir(tracer, mic, source, nreflections, air, speakers_dir=None, speak
         if on_stage:
             on_stage("accumulate", tracer)
         if chain:
-            # one serial sum over all ranks, in ray order (see the docstring)
-            if rank > 0:
-                dist.recv(hist, src=rank - 1)
-            if which & capi.IR_DIFFUSE:
+            # one serial sum over all ranks, in ray order (see the docstring) — SYSTOLIC: the histogram travels in bin-range blocks, rank r
+            # folds block k while rank r + 1 folds block k - 1; a rank keys and sorts its impulses (ir_exact_prepare) before the first
+            # block arrives.  Tracers without the two-step form fold the whole histogram as one block.
+            two_step = hasattr(tracer, "ir_exact_prepare")
+            blocks = max(1, min(int(chain_blocks), (nbins + 15) // 16)) if two_step else 1
+            per = ((nbins + blocks - 1) // blocks + 15) & ~15
+            folds = bool(which & capi.IR_DIFFUSE)
+            if folds:
                 model.configure(tracer, mic, capi.IR_DIFFUSE, empty)
-                tracer.ir_accumulate_tensor(predelay, sample_rate, nbins, mode, hist)
-                tracer.synchronize()
+                if two_step:
+                    tracer.ir_exact_prepare(predelay, sample_rate, nbins)
+            for b0 in range(0, nbins, per):
+                b1 = min(nbins, b0 + per)
+                if rank > 0:
+                    hist[:, :, b0:b1] = _recv_block(hist[:, :, b0:b1], rank - 1)
+                if folds:
+                    if two_step:
+                        tracer.ir_exact_fold_tensor(nbins, b0, b1, hist)
+                    else:
+                        tracer.ir_accumulate_tensor(predelay, sample_rate, nbins, mode, hist)
+                    tracer.synchronize()
+                if rank < world - 1:
+                    _send_block(hist[:, :, b0:b1], rank + 1)
             if rank == world - 1 and (which & capi.IR_IMAGES) and images.shape[0]:
                 model.configure(tracer, mic, capi.IR_IMAGES, images)
                 tracer.ir_accumulate_tensor(predelay, sample_rate, nbins, mode, hist)
                 tracer.synchronize()
-            if rank < world - 1:
-                dist.send(hist, dst=rank + 1)
             dist.broadcast(hist, src=world - 1)
         else:
             tracer.synchronize()

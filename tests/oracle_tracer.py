@@ -73,5 +73,22 @@ class OracleTracer:
             for i in range(att.shape[0]):
                 hist[:, bins[i]] += vol[i]
 
+    def ir_exact_prepare(self, predelay, sample_rate, nbins):
+        """The per-impulse bins of every channel (what rvb_ir_exact_prepare sorts on the GPU)."""
+        self._prepared = []
+        for att in self.channels:
+            att = att.copy()
+            self.oracle.fix_predelay(att, predelay)
+            x = att["time"] * np.float32(sample_rate)
+            f = np.floor(x)
+            self._prepared.append((np.where(x - f >= np.float32(0.5), f + 1, f).astype(np.int64), att["volume"]))
+
+    def ir_exact_fold_tensor(self, nbins, bin_begin, bin_end, tensor):
+        """Bins [bin_begin, bin_end): every bin's impulses in impulse order on top of what the histogram holds."""
+        for ch, (bins, vol) in enumerate(self._prepared):
+            hist = tensor[ch].numpy()
+            for i in np.nonzero((bins >= bin_begin) & (bins < bin_end))[0]:
+                hist[:, bins[i]] += vol[i]
+
     def synchronize(self):
         pass

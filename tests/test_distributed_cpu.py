@@ -19,7 +19,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, out_dir, total_rays, nrefl, capacity=None, chain=False):
+def _worker(rank, world, port, out_dir, total_rays, nrefl, capacity=None, chain=False, hrtf=False, blocks=8):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -45,12 +45,13 @@ def _worker(rank, world, port, out_dir, total_rays, nrefl, capacity=None, chain=
         landed.append(torch.full(shape, float("nan"), dtype=torch.float32))
         return landed[-1]
 
+    model = distributed.HrtfModel(scenes.hrtf_synthetic_table(), (1.0, 0.0, 0.2), (0.0, 1.0, 0.0)) if hrtf else None
     hist, meta = distributed.generate_ir(tracer, info["mic"], info["source"], nrefl, dtypes.AIR_COEFFICIENTS,
                                          [(-1, 0, -1), (1, 0, -1)], [0.5, 0.5], 44100.0, trim_predelay=True,
                                          mode=capi.IR_EXACT, rank=rank, world=world, ray_offset=first, device="cpu", host_out=host_out,
-                                         chain_exact=chain)
+                                         chain_exact=chain, chain_blocks=blocks, model=model)
     assert len(landed) == 1 and meta["host"] is landed[0] and torch.equal(landed[0], hist)     # the host copy is the REDUCED histogram
-    np.savez(os.path.join(out_dir, "rank%d_of%d%s%s.npz" % (rank, world, "" if capacity is None else "_cap%d" % capacity, "_chain" if chain else "")), hist=hist.numpy(), nbins=meta["nbins"],
+    np.savez(os.path.join(out_dir, "rank%d_of%d%s%s%s.npz" % (rank, world, "" if capacity is None else "_cap%d" % capacity, "_chain" if chain else "", "_hrtf" if hrtf else "")), hist=hist.numpy(), nbins=meta["nbins"],
              predelay=meta["predelay"], images=meta["images"])
     if world > 1:
         dist.barrier()
@@ -96,6 +97,18 @@ def test_two_rank_chained_exact_mode_is_bit_identical_to_a_single_process(tmp_pa
     two = [np.load(os.path.join(str(tmp_path), "rank%d_of2_chain.npz" % r)) for r in (0, 1)]
     assert np.array_equal(two[0]["hist"], one["hist"]) and np.array_equal(two[1]["hist"], one["hist"]) and one["hist"].any()
     assert int(two[0]["nbins"]) == int(one["nbins"]) and int(two[1]["images"]) == int(one["images"])
+
+
+def test_two_rank_chained_exact_mode_with_the_hrtf_model_and_three_blocks(tmp_path, oracle):
+    """The same chain with the HRTF listener model (each ear has its own bins) and the histogram travelling in three bin-range
+    blocks: rank 1 folds block k while rank 0 is already folding block k + 1."""
+    import torch.multiprocessing as mp
+    total_rays, nrefl = 64, 8
+    _worker(0, 1, 0, str(tmp_path), total_rays, nrefl, None, False, True)
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), total_rays, nrefl, None, True, True, 3), nprocs=2, join=True)
+    one = np.load(os.path.join(str(tmp_path), "rank0_of1_hrtf.npz"))
+    two = [np.load(os.path.join(str(tmp_path), "rank%d_of2_chain_hrtf.npz" % r)) for r in (0, 1)]
+    assert np.array_equal(two[0]["hist"], one["hist"]) and np.array_equal(two[1]["hist"], one["hist"]) and one["hist"].any()
 
 
 def test_candidate_exchange_overflow_round(tmp_path, oracle):

@@ -110,3 +110,34 @@ def test_ir_dump_roundtrip_cpp_and_python(tool, tmp_path):
     assert subprocess.run([tool, "ir", str(tmp_path / "short.rvbh"), b], capture_output=True).returncode == 3
     with pytest.raises(ValueError):
         formats.read_ir_dump(str(tmp_path / "short.rvbh"))
+
+
+@pytest.mark.gpu
+def test_impulse_dump_of_a_gpu_trace_equals_the_dump_of_the_oracles_impulses(tool, oracle, tmp_path):
+    """SURVEY §8(f)-4 on traced data: the impulses of a GPU trace (reference demo model bedroom.obj, the DIAGNOSTIC path of
+    cmd/main.cpp:270-278: raytrace -> getRawDiffuse -> print_diagnostic, helpers.cpp:19-59) and the CPU oracle's impulses of the same
+    rays give the same impulse.dump, byte for byte; escaped rays' zero slots and the float -> double digits included.  The reference
+    holds no impulse.dump fixture, so the pin is the oracle's impulses through the same writer plus the reader's contract."""
+    from parallel_reverb_raytracer_amd import capi, formats, scenes
+    from parallel_reverb_raytracer_amd.dtypes import AIR_COEFFICIENTS
+    assets = os.path.join(ROOT, "tests", "golden", "assets")
+    scene = scenes.load_obj(os.path.join(assets, "bedroom.obj"), os.path.join(assets, "mat.json"))
+    mic, src, nrays, nrefl = (0.5, 0.2, -0.5), (-0.6, 0.4, 1.0), 96, 24
+    dirs = scenes.sphere_directions(nrays, seed=21)
+    ctx = capi.Context(0)
+    try:
+        ctx.set_scene(scene)
+        ctx.raytrace(mic, src, dirs, nrefl, AIR_COEFFICIENTS)
+        got = ctx.get_raw_diffuse()
+    finally:
+        ctx.close()
+    want, _, _ = oracle.raytrace(scene, mic, src, dirs, nrefl, AIR_COEFFICIENTS)
+    files = {}
+    for name, imp in (("gpu", got), ("oracle", want)):
+        raw, out = str(tmp_path / (name + ".bin")), str(tmp_path / (name + ".dump"))
+        np.ascontiguousarray(imp).tofile(raw)
+        subprocess.check_call([tool, "dump", raw, str(nrays), str(nrefl), out])
+        files[name] = open(out, "rb").read()
+    assert files["gpu"] == files["oracle"] and len(files["gpu"].splitlines()) == nrays
+    pos, vol = formats.read_impulse_dump(str(tmp_path / "gpu.dump"))
+    assert np.array_equal(pos.reshape(-1, 3), got["position"][:, :3]) and np.abs(vol).max() > 0

@@ -70,6 +70,111 @@ def test_shards_on_one_gpu_reproduce_a_single_context_bit_for_bit(case, single, 
         m.close()
 
 
+@pytest.mark.parametrize("blocks", [1, 3, 8])
+def test_systolic_exact_chain_gives_the_same_bytes_for_any_block_count(case, single, blocks):
+    """The exact mode's histogram travels from device to device in bin-range blocks (rvb_multi_set_chain_blocks): device g folds
+    block k while device g + 1 folds block k - 1.  One, three and eight blocks, four "devices" (the test GPU listed four times):
+    speaker and HRTF histograms bit-equal to a single context — the reference's serial order, rayverb.cpp:67-74, :708-714."""
+    from parallel_reverb_raytracer_amd import capi
+    scene, mic, src, dirs, nrefl = case
+    m = capi.MultiContext([0, 0, 0, 0])
+    try:
+        assert m.peer_links() == 0                       # one physical GPU: nothing to enable
+        m.set_chain_blocks(blocks)
+        m.set_scene(scene)
+        m.raytrace(mic, src, dirs, nrefl, AIR_COEFFICIENTS)
+        exact = m.ir_speakers(mic, SPEAKERS[0], SPEAKERS[1], True, 44100.0, capi.IR_EXACT)
+        assert exact.shape == single["speakers"].shape and np.array_equal(exact, single["speakers"])
+        hrtf = m.ir_hrtf(mic, scenes.hrtf_synthetic_table(), (1.0, 0.0, 0.2), (0.0, 1.0, 0.0), True, 44100.0, capi.IR_EXACT)
+        assert hrtf.shape == single["hrtf"].shape and np.array_equal(hrtf, single["hrtf"])
+        diffuse_only = m.ir_speakers(mic, SPEAKERS[0], SPEAKERS[1], True, 44100.0, capi.IR_EXACT, which=capi.IR_DIFFUSE)
+        assert diffuse_only.any()
+    finally:
+        m.close()
+
+
+def test_a_device_without_rays_passes_the_blocks_on(case):
+    """Three rays on four devices: one shard is empty and only hands the histogram's blocks to the next device."""
+    from parallel_reverb_raytracer_amd import capi
+    scene, mic, src, dirs, nrefl = case
+    ctx = capi.Context(0)
+    m = capi.MultiContext([0, 0, 0, 0])
+    try:
+        ctx.set_scene(scene)
+        ctx.raytrace(mic, src, dirs[:3], nrefl, AIR_COEFFICIENTS)
+        ctx.ir_configure_speakers(mic, SPEAKERS[0], SPEAKERS[1], capi.IR_ALL, ctx.get_raw_images(False))
+        want = ctx.ir_download(True, 44100.0, capi.IR_EXACT)
+        m.set_chain_blocks(3)
+        m.set_scene(scene)
+        m.raytrace(mic, src, dirs[:3], nrefl, AIR_COEFFICIENTS)
+        assert sorted(m.shard(i)[1] for i in range(4)) == [0, 1, 1, 1]
+        got = m.ir_speakers(mic, SPEAKERS[0], SPEAKERS[1], True, 44100.0, capi.IR_EXACT)
+        assert got.shape == want.shape and np.array_equal(got, want)
+    finally:
+        m.close()
+        ctx.close()
+
+
+def test_exact_mode_in_two_steps_equals_one_call(case, single):
+    """rvb_ir_exact_prepare + rvb_ir_exact_fold over all bins in five uneven ranges = rvb_ir_accumulate(RVB_IR_EXACT); a call that reuses
+    the sort buffers in between voids the prepared list and the fold refuses."""
+    import torch
+    from parallel_reverb_raytracer_amd import capi
+    scene, mic, src, dirs, nrefl = case
+    ctx = capi.Context(0)
+    try:
+        ctx.set_scene(scene)
+        ctx.raytrace(mic, src, dirs, nrefl, AIR_COEFFICIENTS)
+        for name, configure in (("speakers", lambda: ctx.ir_configure_speakers(mic, SPEAKERS[0], SPEAKERS[1], capi.IR_ALL, single["images"])),
+                                ("hrtf", lambda: ctx.ir_configure_hrtf(mic, scenes.hrtf_synthetic_table(), (1.0, 0.0, 0.2), (0.0, 1.0, 0.0), capi.IR_ALL, single["images"]))):
+            configure()
+            lo, hi = ctx.ir_time_range()
+            nbins = ctx.ir_bins(hi, lo, 44100.0)
+            assert nbins == single[name].shape[2]
+            hist = torch.zeros((2, 8, nbins), device="cuda", dtype=torch.float32)
+            ctx.ir_exact_prepare(lo, 44100.0, nbins)
+            cuts = [0, 17, nbins // 3, nbins // 3 + 1, nbins - 5, nbins]
+            for b0, b1 in zip(cuts[:-1], cuts[1:]):
+                ctx.ir_exact_fold_tensor(nbins, b0, b1, hist)
+            ctx.synchronize()
+            assert np.array_equal(hist.cpu().numpy(), single[name]), name
+            configure()                                   # voids the prepared list
+            with pytest.raises(capi.RvbError):
+                ctx.ir_exact_fold_tensor(nbins, 0, nbins, hist)
+    finally:
+        ctx.close()
+
+
+def test_histogram_leaves_for_the_host_in_bin_ranges(case, single):
+    """rvb_ir_accumulate_export: the exact-mode histogram is copied to pinned host memory bin range by bin range behind the folds
+    (1, 3, 8 ranges and the fast mode's single copy): same bytes as the device histogram, and as ir_download."""
+    import torch
+    from parallel_reverb_raytracer_amd import capi
+    scene, mic, src, dirs, nrefl = case
+    ctx = capi.Context(0)
+    try:
+        ctx.set_scene(scene)
+        ctx.raytrace(mic, src, dirs, nrefl, AIR_COEFFICIENTS)
+        ctx.ir_configure_speakers(mic, SPEAKERS[0], SPEAKERS[1], capi.IR_ALL, single["images"])
+        lo, hi = ctx.ir_time_range()
+        nbins = ctx.ir_bins(hi, lo, 44100.0)
+        for slices in (1, 3, 8):
+            hist = torch.zeros((2, 8, nbins), device="cuda", dtype=torch.float32)
+            host = torch.full((2, 8, nbins), -1.0, dtype=torch.float32).pin_memory()
+            ctx.ir_accumulate_export_tensor(lo, 44100.0, nbins, capi.IR_EXACT, hist, host, slices)
+            ctx.synchronize()
+            ctx.synchronize_exports()
+            assert np.array_equal(host.numpy(), single["speakers"]) and np.array_equal(hist.cpu().numpy(), single["speakers"]), slices
+        hist = torch.zeros((2, 8, nbins), device="cuda", dtype=torch.float32)
+        host = torch.full((2, 8, nbins), -1.0, dtype=torch.float32).pin_memory()
+        ctx.ir_accumulate_export_tensor(lo, 44100.0, nbins, capi.IR_FAST, hist, host)
+        ctx.synchronize()
+        ctx.synchronize_exports()
+        assert np.array_equal(host.numpy(), hist.cpu().numpy()) and host.numpy().any()
+    finally:
+        ctx.close()
+
+
 def test_rccl_all_reduce_is_bound_and_runs(case, single):
     """librccl.so loaded at run time, one communicator over the device list, ncclAllReduce in place on the histogram: with one
     device the sum is the identity, so the result must equal the plain fast-mode histogram up to its own atomics order."""
