@@ -41,7 +41,7 @@ from parallel_reverb_raytracer_amd import capi, distributed, dtypes, scenes  # n
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 # the guide's vector issue rate: v_fma_f32 (wave64) 2 cycles on each of 256 x 4 SIMDs at 2.4 GHz
 VALU_FMA_PEAK_GINST = 256 * 4 * 2.4 / 2
-PMC_FILE = "r03_pmc_n1.json"      # committed PMC passes of this command (tools/profile.sh): instruction mix, lane utilisation, HBM bytes
+PMC_FILE = "r04_pmc_n1.json"      # committed PMC passes of this command (tools/profile.sh): instruction mix, lane utilisation, HBM bytes
 BYTES_PER_BOUNCE = 69.75          # 64 B Impulse per bounce + (16 B direction + 10 x 72 B image slots) per ray at 128 bounces
 
 
@@ -67,8 +67,10 @@ def parse():
                    "to one GPU; their binning stages run one after the other) instead of all-reducing their own serial sums")
     p.add_argument("--no-host-copy", action="store_true", help="leave the finished histograms in HBM (the round-1/2 metric; diagnostic)")
     p.add_argument("--master-port", type=int, default=0, help="rendezvous port when bench.py starts its own ranks (0: a free one)")
-    p.add_argument("--native", action="store_true", help="one GPU: the timed region is driven by the pipeline behind the C-ABI (rvb_pipeline_*, "
-                   "csrc/pipeline.hip: what a C++ caller gets) instead of distributed.IrPipeline; without the flag it is reported beside the line as native_pipeline")
+    p.add_argument("--python-pipeline", action="store_true", help="one GPU: drive the timed region with distributed.IrPipeline (Python over the C-ABI) "
+                   "instead of the pipeline behind the C-ABI (rvb_pipeline_*, csrc/pipeline.hip: what a C++ caller gets — the default on one GPU; with "
+                   "several ranks the Python pipeline runs, it carries the torch.distributed collectives); the other one is reported beside the line")
+    p.add_argument("--native", action="store_true", help="(default on one GPU since round 4; kept so that older command lines still run)")
     p.add_argument("--contexts", type=int, default=4, help="contexts per GPU that take turns (4: the traces of IRs i+2, i+3 are enqueued "
                    "together, beside the grouping / binning / host stages of IRs i, i+1; 2: plain alternation; 1: strictly one IR at a time)")
     return p.parse_args()
@@ -166,6 +168,7 @@ def launch_ranks(args):
 
 def main():
     args = parse()
+    args.native = not args.python_pipeline
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args)                                # does not return
     # Rank 0 owes the driver ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner to
@@ -327,26 +330,28 @@ def main():
     def timed_native(steps, warmup, native_mode):
         """The same region through rvb_pipeline_* (csrc/pipeline.hip): jobs submitted a few ahead of the results taken, every histogram
         in the pipeline's pinned ring when rvb_pipeline_next returns.  Returns (seconds, last histogram as a tensor, info)."""
-        native = capi.Pipeline(contexts)
+        native = capi.Pipeline(contexts, group=int(os.environ.get("RVB_PIPELINE_GROUP", 0)))
         try:
             native.configure_speakers(speakers_dir, speakers_coeff, nrefl, dtypes.AIR_COEFFICIENTS, sr, True, native_mode)
 
             def run(count):
                 submitted = taken = 0
-                last = None
+                last = []
                 while taken < count:
                     while submitted < count and native.pending() < 2 * len(contexts):
                         native.submit(mic, src)
                         submitted += 1
-                    last = native.next(copy=False)
+                    last = (last + [native.next(copy=False)])[-len(contexts):]      # (a result stays valid until `contexts` more have been taken)
                     taken += 1
                 return last
             run(warmup)
             fence()
             t0 = time.perf_counter()
-            view, info = run(steps)
+            last = run(steps)
             fence()
             seconds = time.perf_counter() - t0
+            state["native_landed"] = [torch.from_numpy(v.copy()) for v, _ in last]      # the region's last histograms as they landed in the pinned ring
+            view, info = last[-1]
             return seconds, torch.from_numpy(view.copy()), info
         finally:
             native.close()
@@ -380,6 +385,8 @@ def main():
     timed_hist = (state["host"] if to_host else state["hist"].cpu()).clone()
     # every buffer of the ring holds one of the region's last 2 x contexts IRs as it landed on the host (the timed IRs are identical jobs)
     landed = [h.clone() for h in host_ring] if to_host and args.steps >= len(host_ring) else []
+    if args.native and world == 1 and not grouped:
+        landed = state.pop("native_landed", [])
     solo_hist, _ = distributed.generate_ir(ctx, *trace_args, **dict(ir_kwargs(None), host_out=None))
     fence()
     solo_host = solo_hist.cpu()
@@ -403,8 +410,11 @@ def main():
     other_mode, comparison = None, None
     if not args.no_extras:
         other = capi.IR_EXACT if mode == capi.IR_FAST else capi.IR_FAST
-        pipeline.run(2, trace_args, ir_kwargs(None, other), keep)
-        other_elapsed = timed(args.steps, ir_kwargs(None, other))
+        if args.native and world == 1 and not grouped:      # (the same driver as the headline)
+            other_elapsed = timed_native(args.steps, 2, other)[0]
+        else:
+            pipeline.run(2, trace_args, ir_kwargs(None, other), keep)
+            other_elapsed = timed(args.steps, ir_kwargs(None, other))
         other_mode = {"mode": "exact" if other == capi.IR_EXACT else "fast", "value": bounces_per_step / (other_elapsed / args.steps),
                       "ms_per_step": other_elapsed / args.steps * 1e3}
         h_fast, _ = distributed.generate_ir(ctx, *trace_args, **ir_kwargs(None, capi.IR_FAST))
@@ -414,6 +424,7 @@ def main():
             comparison = fast_vs_exact(h_fast, h_exact)
         del h_fast, h_exact
 
+    python_leg = None
     if not args.no_extras and not args.native and world == 1 and not grouped:
         # the same region driven through the C-ABI's own pipeline (what a C++ caller gets), its last histogram held against a solo IR
         n_elapsed, n_hist, n_info = timed_native(args.steps, 4, mode)
@@ -422,6 +433,12 @@ def main():
         native_leg = {"what": "rvb_pipeline_* (csrc/pipeline.hip): the schedule behind the C-ABI, driven through ctypes", "ms_per_step": n_elapsed / args.steps * 1e3,
                       "value": bounces_per_step / (n_elapsed / args.steps), "last_histogram_equals_solo_ir": bool(torch.equal(n_hist, check.cpu()))}
         del check, n_hist
+    if not args.no_extras and args.native and world == 1 and not grouped:
+        # ... and the Python driver (distributed.IrPipeline: what N > 1 ranks run, with the collectives) beside the native one
+        pipeline.run(4, trace_args, ir_kwargs(None), keep)
+        p_elapsed = timed(args.steps, ir_kwargs(None))
+        python_leg = {"what": "distributed.IrPipeline (Python over the C-ABI), same schedule", "ms_per_step": p_elapsed / args.steps * 1e3,
+                      "value": bounces_per_step / (p_elapsed / args.steps)}
     attenuate_probe, api_flow = None, None
     if rank == 0 and not args.no_extras:
         # the materialised attenuate kernel (reference kernel `attenuate`, what SpeakerAttenuator::attenuate launches per
@@ -468,8 +485,9 @@ def main():
         from_profile = "profiles/%s (rocprofv3 --pmc passes of this command, per launch)" % PMC_FILE
 
         def hbm_traffic(k):
+            # calibrated: FETCH_SIZE x 2 for streaming kernels, x 1 for gathers (tools/fetch_calibration.hip, profiles/r04_fetch_calibration_n1.txt)
             v = pmc.get(k, {})
-            return v.get("hbm_bytes_per_ir", v.get("hbm_bytes_per_launch"))
+            return v.get("hbm_bytes_calibrated_per_ir", v.get("hbm_bytes_calibrated_per_launch", v.get("hbm_bytes_per_ir", v.get("hbm_bytes_per_launch"))))
 
         # the contract's roofline line, for the dominant kernel: the trace stage's algorithmic bytes (69.75 B per
         # ray-bounce, ALL of them charged to this one kernel) over its launch duration, against HBM.  A ray's bounces are a dependent
@@ -478,7 +496,8 @@ def main():
         ach = BYTES_PER_BOUNCE * nrays * nrefl / (solo[dominant] * 1e-3) / 1e9
         roofline = {"kernel": dominant, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": hbm_traffic(dominant),
-                    "traffic_source": from_profile + ", (2 x FETCH_SIZE + WRITE_SIZE) x 1024" if hbm_traffic(dominant) else None,
+                    "traffic_source": from_profile + ", (FETCH_SIZE + WRITE_SIZE) x 1024: a gather kernel, whose FETCH_SIZE is calibrated at x 1 "
+                                      "(profiles/r04_fetch_calibration_n1.txt; the guide's x 2 holds for wide streaming reads)" if hbm_traffic(dominant) else None,
                     "algorithmic_bytes_per_launch": BYTES_PER_BOUNCE * nrays * nrefl, "avg_launch_ms": solo[dominant],
                     "elapsed_ms_in_timed_region": avg.get(dominant),
                     "note": "avg_launch_ms: HIP events around the launch on the context's stream with one IR on the GPU; the whole trace "
@@ -567,7 +586,7 @@ def main():
             "fast_mode" if args.mode == "exact" else "exact_mode": other_mode, "fast_vs_exact": comparison, "api_flow": api_flow,
             "driver": ("rvb_pipeline_* (csrc/pipeline.hip, the C-ABI's own pipeline, through ctypes)" if args.native and world == 1 and not grouped
                        else "distributed.IrPipeline (Python over the C-ABI; the N > 1 form with torch.distributed collectives)"),
-            "native_pipeline": native_leg,
+            "native_pipeline": native_leg, "python_pipeline": python_leg,
             "trace_only_ray_bounces_per_sec": (nrays * nrefl) / (trace_ms * 1e-3) if trace_ms else None,
             "executed_bounces_rank0": int(executed), "nominal_bounces_rank0": nrays * nrefl,
             "kernel_elapsed_ms_timed_region": avg, "kernel_ms": solo, "nbins": state["nbins"], "image_sources": state["images"], "predelay_s": state["predelay"],

@@ -501,11 +501,22 @@ __global__ __launch_bounds__(64) void ordered_sum_kernel(ModelDev m, uint32_t fi
                                                          uint64_t ndiffuse, const rvb_impulse * __restrict__ images,
                                                          const uint32_t * __restrict__ values,
                                                          const uint32_t * __restrict__ starts, const uint32_t * __restrict__ ends,
-                                                         uint64_t nbins, uint64_t bin_begin, uint64_t bin_end, float * __restrict__ hist)
+                                                         uint64_t nbins, uint64_t bin_begin, uint64_t bin_end, float * __restrict__ hist, uint32_t xcd_chunk)
 {
     // (bins [bin_begin, bin_end) of this launch: the caller may fold the histogram bin range by bin range, each range leaving for
     // the host as soon as it is final — rvb_ir_accumulate_export)
-    const uint64_t t = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    // xcd_chunk != 0: workgroups b and b + 8 share an XCD (round-robin dispatch, speed only), so a run of `xcd_chunk` consecutive
+    // workgroups' bins is given to the eight-apart workgroups of ONE XCD: the two 64-byte records of a 128-byte line (bounces b and
+    // b + 1 of a ray, some 1 500 bins apart at workload C2) are then gathered through the same L2, the second one from cache.
+    uint32_t block = blockIdx.x;
+    if (xcd_chunk) {
+        const uint32_t span = 8u * xcd_chunk;
+        if (block / span < gridDim.x / span) {
+            const uint32_t within = block % span;
+            block = block - within + (within & 7u) * xcd_chunk + (within >> 3);
+        }
+    }
+    const uint64_t t = (uint64_t) block * blockDim.x + threadIdx.x;
     const uint64_t bin = bin_begin + (t >> 1);
     const uint32_t half = (uint32_t) t & 1u;
     if (bin >= bin_end)
@@ -756,8 +767,9 @@ void rvb_launch_ordered_sum(const AttenuationModel & m, uint32_t first_channel, 
     if (nbins == 0 || n == 0 || bin_begin >= bin_end) return;
     const dim3 grid((unsigned) ((2 * (bin_end - bin_begin) + 63) / 64)), block(64);      // two lanes per bin
     const ModelDev md = make_model(m);
+    static const uint32_t xcd_chunk = getenv("RVB_SUM_XCD_CHUNK") ? (uint32_t) atoi(getenv("RVB_SUM_XCD_CHUNK")) : 0u;      // workgroups per XCD run, 0 = off
 #define RVB_SUM(HRTF, NCH) hipLaunchKernelGGL((ordered_sum_kernel<HRTF, NCH>), grid, block, 0, s, md, first_channel, diffuse, ndiffuse, \
-                                              images, sorted_values, starts, ends, nbins, bin_begin, bin_end, hist)
+                                              images, sorted_values, starts, ends, nbins, bin_begin, bin_end, hist, xcd_chunk)
     if (m.hrtf) { RVB_SUM(true, 1); return; }
     switch (nchannels) {                       // speaker channels of one sorted list
     case 1: RVB_SUM(false, 1); break;

@@ -1080,9 +1080,27 @@ __global__ __launch_bounds__(WAVE, RVB_PAIR_WAVES) void path_pair_group_kernel(T
 // other two path kernels (tests/test_gpu_parity.py runs every trace case with all three).
 #define LANE_RAYS 64
 typedef __attribute__((address_space(3))) uint32_t * lds_u32_ptr;
+typedef __attribute__((address_space(3))) void * lds_void_ptr;
+typedef const __attribute__((address_space(1))) void * global_void_ptr;
 #ifndef RVB_LANE_WAVES
 #define RVB_LANE_WAVES 4            // waves per SIMD the register budget allows (128 VGPRs)
 #endif
+// Node fetch of the one-lane kernel.  A lane that reads the 64 bytes of ITS node with four 16-byte loads makes four L1 accesses per
+// node visit (the texture addresser coalesces the lanes of ONE instruction, not the instructions of one lane): PMC at 800 k rays —
+// 87 L1 accesses per ray-bounce against 50 (pairs) and 33 (quads), TA stalled by the L1 a quarter of its busy time, and the kernel
+// slower than the pairs although it issues 27 % fewer vector instructions (profiles/r04_path_pmc_by_lanes_800k_rays_n1.txt).
+// RVB_LANE_COOP = 1: the four lanes of a QUAD fetch each other's nodes — in load s every lane of the quad reads "its" child (16 bytes)
+// of the node of the quad's lane s, one contiguous 64-byte access per quad like the quad kernel's — straight into LDS
+// (global_load_lds_dwordx4: no registers in between), and each lane then reads its own node's four children back with four
+// ds_read_b128.  Load s of the wave lands at stage + s * RVB_LANE_STAGE_STRIDE + lane * 16 (the extra 16 bytes per load put the four
+// reads of a quad's lanes on different banks).
+// MEASURED, and slower still (profiles/r04_rays_sweep_by_lanes_n1.txt): 800 k rays 3.02 ms per 100 k rays against 2.35 with the plain
+// loads (pairs 2.07), 100 k rays 4.48 against 3.94 — the detour through LDS adds a dependent round trip to every node step and its 4 KB
+// of LDS per wave cost a fifth of the occupancy.  Off; the shipped kernels stay the pair / quad kernels.
+#ifndef RVB_LANE_COOP
+#define RVB_LANE_COOP 0
+#endif
+#define RVB_LANE_STAGE_STRIDE 1040u
 template <bool SURF_LDS>
 __device__ __forceinline__ void path_lane_body(const TraceArgs & a, const uint32_t block)
 {
@@ -1095,9 +1113,15 @@ __device__ __forceinline__ void path_lane_body(const TraceArgs & a, const uint32
     uint32_t * const after_stack = stack_lds + (a.stack_entries + 1u) * LANE_RAYS;
     const lds_float4_ptr surf_lds = stage_surfaces(a, after_stack);
     uint16_t * const key_row = reinterpret_cast<uint16_t *>(after_stack + 16u * a.lds_surfaces) + lane * RVB_KEY_RUN;
-    if (ray >= a.nrays)
+    // (behind the key runs when there are any: rvb_lane_lds_bytes) the landing area of the cooperative node fetch
+    uint32_t * const stage = after_stack + 16u * a.lds_surfaces + (a.sort_keys16 ? LANE_RAYS * RVB_KEY_RUN / 2u : 0u);
+    const bool in_range = ray < a.nrays;
+#if !RVB_LANE_COOP
+    if (!in_range)
         return;
-    uint32_t pair = 0, local = (uint32_t) ray;
+#endif
+    // (with the cooperative fetch the lanes behind the last ray stay: they carry no ray, but fetch for their quad's other lanes)
+    uint32_t pair = 0, local = in_range ? (uint32_t) ray : 0u;
     v3 o = ld3(a.source);
     if (a.npairs > 1) {
         pair = (uint32_t) ray / a.rays_per_pair;
@@ -1130,7 +1154,7 @@ __device__ __forceinline__ void path_lane_body(const TraceArgs & a, const uint32
         selx = slab_selector(ix); sely = slab_selector(iy); selz = slab_selector(iz); \
         best_key = NO_HIT_KEY; sp = bottom; ref = 0;                              \
     }
-    if (index < a.nreflections) RVB_RESET_QUERY()
+    if (in_range && index < a.nreflections) RVB_RESET_QUERY()
     for (;;) {
         RVB_MARK("vote");
         const unsigned long long m_node = __builtin_amdgcn_ballot_w64((int32_t) ref >= 0);
@@ -1141,8 +1165,30 @@ __device__ __forceinline__ void path_lane_body(const TraceArgs & a, const uint32
             break;
         if (n_node >= n_leaf && n_node >= n_done) {
             RVB_MARK("node");
+#if RVB_LANE_COOP
+            {
+                // every lane of the wave is here (the branch is wave-uniform): load s fetches the node of each quad's lane s, if that lane
+                // is at a node (the condition is quad-uniform: whole quads skip the load)
+                const uint32_t child = 16u * (lane & 3u);
+#define RVB_COOP_LOAD(S)                                                                                                         \
+                {                                                                                                                \
+                    const uint32_t ref_s = quad_bcast_u<S>(ref);                                                                 \
+                    if ((int32_t) ref_s >= 0)                                                                                    \
+                        __builtin_amdgcn_global_load_lds((global_void_ptr) (node_base + (ref_s | child)),                        \
+                                                         (lds_void_ptr) (stage + S * (RVB_LANE_STAGE_STRIDE / 4u)), 16, 0, 0);   \
+                }
+                RVB_COOP_LOAD(0) RVB_COOP_LOAD(1) RVB_COOP_LOAD(2) RVB_COOP_LOAD(3)
+#undef RVB_COOP_LOAD
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the LDS-DMA loads are not in the compiler's books
+            }
+#endif
             if ((int32_t) ref >= 0) {
+#if RVB_LANE_COOP
+                // this lane's node: load (lane & 3) of the wave, this quad's 64 bytes
+                const uint4 * np = reinterpret_cast<const uint4 *>(stage + (lane & 3u) * (RVB_LANE_STAGE_STRIDE / 4u) + (lane & ~3u) * 4u);
+#else
                 const uint4 * np = reinterpret_cast<const uint4 *>(node_base + ref);
+#endif
                 const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
                 const float limit = fmaf(__uint_as_float((uint32_t) (best_key >> 32)), cull_scale, a.scene.cull_abs);
                 float tn0, tn1, tn2, tn3;
@@ -1250,6 +1296,8 @@ __device__ __forceinline__ void path_lane_body(const TraceArgs & a, const uint32
         RVB_MARK("loop_end");
     }
 #undef RVB_RESET_QUERY
+    if (!in_range)
+        return;
     // an escaped ray leaves its remaining slots zero-filled and their grouping keys "no record" (finish_escaped_ray)
     if (index < a.nreflections) {
         const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -1787,7 +1835,7 @@ static size_t rvb_pair_lds_bytes(const TraceArgs & a)
 static size_t rvb_lane_lds_bytes(const TraceArgs & a)
 {
     return (a.stack_entries + 1u) * LANE_RAYS * sizeof(uint32_t) + (size_t) a.lds_surfaces * sizeof(rvb_surface)
-           + (a.sort_keys16 ? LANE_RAYS * RVB_KEY_RUN * sizeof(uint16_t) : 0u);
+           + (a.sort_keys16 ? LANE_RAYS * RVB_KEY_RUN * sizeof(uint16_t) : 0u) + (RVB_LANE_COOP ? 4u * RVB_LANE_STAGE_STRIDE : 0u);
 }
 
 uint32_t rvb_lds_surfaces(uint32_t stack_entries, uint64_t nsurfaces)

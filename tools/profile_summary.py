@@ -10,7 +10,7 @@ import sys
 
 tag = sys.argv[1]
 out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
-SHORT = ["path_kernel", "path_pair_group_kernel", "path_pair_kernel", "image_plan_kernel", "image_check_kernel", "shadow_kernel", "shadow_pair_kernel",
+SHORT = ["path_kernel", "path_lane_group_kernel", "path_pair_group_kernel", "path_pair_kernel", "image_plan_kernel", "image_check_kernel", "shadow_kernel", "shadow_pair_kernel",
          "bin_keys_hrtf_kernel", "ordered_sum_hrtf_kernel", "histogram_fast_kernel", "histogram_transpose_kernel", "attenuate_kernel",
          "time_range_kernel", "bin_keys_kernel", "ordered_sum_kernel", "radix_sort_onesweep_iteration", "radix_sort_onesweep_global_offsets"]
 
@@ -72,9 +72,16 @@ for d in sorted(glob.glob(os.path.join(out, tag + "_pmc_*"))):
             pmc[s].setdefault("_launches", len(disp))
             if c == "SQ_INSTS_VALU":
                 pmc[s]["SQ_INSTS_VALU_all_launches"] = total
+# FETCH_SIZE tallies a wide coalesced streaming read at HALF its bytes and a gather of 64-byte records at its TRUE bytes (tools/fetch_calibration.hip,
+# profiles/r04_fetch_calibration_n1.txt: 1 GiB streamed -> 512 MiB, 512 MiB of random 64-byte records -> 510 MiB, 1 GiB of records read and rewritten in
+# place -> 1 067 MiB fetched, 1 072 MiB written): the x2 of the guide applies to the STREAMING kernels only
+STREAMING = {"radix_sort_onesweep_iteration", "radix_sort_onesweep_global_offsets", "bin_keys_kernel", "bin_keys_hrtf_kernel", "bin_starts_kernel", "attenuate_kernel",
+             "histogram_fast_kernel", "histogram_transpose_kernel", "time_range_kernel"}
 for s, c in pmc.items():
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-        c["hbm_bytes_per_launch"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+        c["hbm_bytes_per_launch"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0        # the guide's correction for every kernel: an upper bound for gathers
+        c["fetch_factor_calibrated"] = 2.0 if s in STREAMING else 1.0
+        c["hbm_bytes_calibrated_per_launch"] = (c["fetch_factor_calibrated"] * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
     if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c and c["TCC_HIT_sum"] + c["TCC_MISS_sum"] > 0:
         c["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
     if "SQ_ACTIVE_INST_VALU" in c and "SQ_BUSY_CYCLES" in c and c["SQ_BUSY_CYCLES"] > 0:
@@ -108,6 +115,7 @@ irs = pmc.get("path_kernel", {}).get("_launches", 0) + pmc.get("path_pair_kernel
 for c in pmc.values():                                   # a kernel launched more than once per IR (binning: diffuse + images)
     if "hbm_bytes_per_launch" in c and irs:
         c["hbm_bytes_per_ir"] = c["hbm_bytes_per_launch"] * c.get("_launches", irs) / irs
+        c["hbm_bytes_calibrated_per_ir"] = c["hbm_bytes_calibrated_per_launch"] * c.get("_launches", irs) / irs
 step_kernels = [k for k in pmc if k != "attenuate_kernel"]          # the attenuate probe runs outside the timed steps
 valu_per_ir = sum(pmc[k].get("SQ_INSTS_VALU_all_launches", 0.0) for k in step_kernels) / irs if irs else None
 json.dump({"irs_in_command": irs, "valu_wave_instructions_per_ir": valu_per_ir, "_how": "tools/profile.sh %s: rocprofv3 --kernel-trace --pmc <one set per pass> -- python3 bench.py --steps 3 --warmup 1 "

@@ -20,7 +20,9 @@ from parallel_reverb_raytracer_amd import capi, dtypes, scenes  # noqa: E402
 def main():
     counts = [int(x) for x in sys.argv[1:]] or [100000, 200000]
     nrefl = int(os.environ.get("SWEEP_REFLECTIONS", "128"))
-    (scene, info) = scenes.cathedral(int(os.environ.get("SWEEP_TRIANGLES", "75000")))
+    # SWEEP_SCENE=atrium: the C4 stand-in (SWEEP_TRIANGLES=262000 SWEEP_REFLECTIONS=256 for the configuration itself)
+    make = {"cathedral": scenes.cathedral, "atrium": scenes.atrium, "hall": scenes.concert_hall}[os.environ.get("SWEEP_SCENE", "cathedral")]
+    (scene, info) = make(int(os.environ.get("SWEEP_TRIANGLES", "75000")))
     group = int(os.environ.get("SWEEP_GROUP", "1"))      # > 1: that many contexts, n rays each, ONE path-kernel launch (rvb_trace_group)
     ctxs = [capi.Context(0) for _ in range(group)]
     for c in ctxs:
