@@ -615,7 +615,7 @@ static int trace_finish(rvb_ctx * ctx, TracePlan & plan, const float * mics)
         ctx->end_timing();
     }
     RVB_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_done, 0));
-    ctx->begin_timing(rvb_shadow_lanes() == 2 ? "shadow_pair_kernel" : "shadow_kernel");
+    ctx->begin_timing(rvb_shadow_lanes() == 2 ? "shadow_pair_kernel" : (rvb_shadow_lanes() == 1 ? "shadow_lane_kernel" : "shadow_kernel"));
     rvb_launch_shadow(a, ctx->stream);
     ctx->end_timing();
     RVB_HIP(ctx, hipGetLastError());

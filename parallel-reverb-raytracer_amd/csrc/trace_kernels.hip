@@ -1815,6 +1815,150 @@ __global__ __launch_bounds__(WAVE, RVB_SHADOW_PAIR_WAVES) void shadow_pair_kerne
     }
 }
 
+// shadow_pair_kernel with ONE lane per record (round 4, RVB_SHADOW_LANES=1): 64 records per wave pass, every lane walks its own any-hit
+// query — four children and up to four triangles per step — with its own LDS stack column, nothing exchanged between lanes.  The records of
+// a wave are neighbours in grouped order (same wall, same microphone), so unlike the path kernel's rays the lanes read mostly the SAME
+// nodes: few distinct lines per load instruction.  Same operations on the same values as the pair kernel: same bytes
+// (tests/test_gpu_parity.py::test_quad_shadow_kernel_gives_the_same_bytes runs it in a child process).  MEASURED at workload C2
+// (profiles/r04_shadow_lanes_n1.txt): 2.12 ms against 1.26 (pairs) and 1.47 (quads) per 100 k rays x 128, the bench pipeline 5.40 against
+// 4.42 ms per IR — like the one-lane path kernel it pays for its shorter instruction stream in 16-byte-per-lane loads (a leaf step alone is
+// twelve of them per lane).  Kept for measurements only; the shipped form is two lanes per record.
+template <bool SURF_LDS>
+__global__ __launch_bounds__(WAVE, RVB_LANE_WAVES) void shadow_lane_kernel(TraceArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t stack_lds[];   // [stack_entries + 1][64], surface table
+    const uint32_t lane = threadIdx.x;
+    const lds_float4_ptr surf_lds = stage_surfaces(a, stack_lds + (a.stack_entries + 1u) * LANE_RAYS);
+    const uint64_t stride = (uint64_t) gridDim.x * LANE_RAYS, total = a.nrays * (uint64_t) a.nreflections;
+    const char * node_base = reinterpret_cast<const char *>(a.scene.nodes);
+    const char * tri_base = reinterpret_cast<const char *>(a.scene.tris);
+    const float neg_cull = -a.scene.cull_abs;
+    const lds_u32_ptr bottom = (lds_u32_ptr) stack_lds + lane;
+    v3 mic = ld3(a.mic);
+    float tmin = __builtin_inff(), tmax_seen = 0.0f;
+    for (uint64_t g = (uint64_t) blockIdx.x * LANE_RAYS + lane; g < total; g += stride) {
+        float4 * rec = reinterpret_cast<float4 *>(a.impulses + (a.sort_order ? (uint64_t) a.sort_order[g] : g));
+        const float4 vol_lo = load_stream(rec + 0), vol_hi = load_stream(rec + 1), geo = load_stream(rec + 2), aux = load_stream(rec + 3);
+        const uint32_t tag = __float_as_uint(aux.w);
+        if (tag == 0u)
+            continue;                             // ray had already escaped: slot keeps its zero fill
+        uint32_t pair = 0;
+        if (a.npairs > 1) {
+            const float4 m4 = a.pair_mics[tag - 1u];
+            mic = mk3(m4.x, m4.y, m4.z);
+            pair = tag - 1u;
+        }
+        const float new_dist = aux.x, threshold = aux.y;
+        const float4 * shade = reinterpret_cast<const float4 *>(a.scene.shade + __float_as_uint(aux.z));
+        const float4 sh = shade[0];
+        const uint32_t skip_ref = __float_as_uint(shade[1].x);
+        const uint32_t surface = __float_as_uint(sh.w);
+        const v3 p = mk3(geo.x, geo.y, geo.z);
+        const float diff = geo.w;
+        const v3 b2p = mic - p;                   // kernel.cpp:282-286
+        const float mag = length3(b2p);
+        const v3 dir = normalize3(b2p);
+        const uint32_t skip = fabsf(dot3(mk3(sh.x, sh.y, sh.z), dir)) > threshold ? skip_ref : RVB_BVH_EMPTY;
+        // any hit with EPSILON < distance <= mag? (traverse_pair_any with one lane: the lowest hit child is entered, the others pushed)
+        bool blocked = false;
+        {
+            const float limit = fmaf(mag, 1.0f + a.scene.cull_rel, a.scene.cull_abs);
+            const float ix = clamp_inv(dir.x), iy = clamp_inv(dir.y), iz = clamp_inv(dir.z);
+            const float oix = p.x * ix, oiy = p.y * iy, oiz = p.z * iz;
+            const uint32_t selx = slab_selector(ix), sely = slab_selector(iy), selz = slab_selector(iz);
+            lds_u32_ptr sp = bottom;
+            uint32_t ref = 0;
+            for (;;) {
+                while (!(ref & RVB_BVH_LEAF)) {
+                    const uint4 * np = reinterpret_cast<const uint4 *>(node_base + ref);
+                    const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+                    float tn;
+                    const bool ok0 = slab_select(n0, ix, iy, iz, oix, oiy, oiz, selx, sely, selz, limit, neg_cull, skip, tn);
+                    const bool ok1 = slab_select(n1, ix, iy, iz, oix, oiy, oiz, selx, sely, selz, limit, neg_cull, skip, tn);
+                    const bool ok2 = slab_select(n2, ix, iy, iz, oix, oiy, oiz, selx, sely, selz, limit, neg_cull, skip, tn);
+                    const bool ok3 = slab_select(n3, ix, iy, iz, oix, oiy, oiz, selx, sely, selz, limit, neg_cull, skip, tn);
+                    // the lowest hit child is entered; the others go on the stack in child order (store, then advance if kept)
+                    const bool first0 = ok0, first1 = ok1 && !ok0, first2 = ok2 && !(ok0 || ok1), first3 = ok3 && !(ok0 || ok1 || ok2);
+                    *sp = n1.w; sp += (ok1 && !first1) ? LANE_RAYS : 0;
+                    *sp = n2.w; sp += (ok2 && !first2) ? LANE_RAYS : 0;
+                    *sp = n3.w; sp += (ok3 && !first3) ? LANE_RAYS : 0;
+                    if (first0) ref = n0.w;
+                    else if (first1) ref = n1.w;
+                    else if (first2) ref = n2.w;
+                    else if (first3) ref = n3.w;
+                    else if (sp != bottom) { sp -= LANE_RAYS; ref = *sp; }
+                    else ref = NONE;
+                }
+                if (ref == NONE)
+                    break;
+                const uint32_t first = ref & 0x0FFFFFFFu;
+                const uint32_t count = ((ref >> 28) & 7u) + 1u;
+                const float4 * tp0 = reinterpret_cast<const float4 *>(tri_base + tri_byte_offset(first));
+                const float4 * tp1 = reinterpret_cast<const float4 *>(tri_base + tri_byte_offset(first + (1u < count ? 1u : 0u)));
+                const float4 * tp2 = reinterpret_cast<const float4 *>(tri_base + tri_byte_offset(first + (2u < count ? 2u : 0u)));
+                const float4 * tp3 = reinterpret_cast<const float4 *>(tri_base + tri_byte_offset(first + (3u < count ? 3u : 0u)));
+                float4 ta = tp0[0], tb = tp0[1], tc = tp0[2], ua = tp1[0], ub = tp1[1], uc = tp1[2];
+                float4 va = tp2[0], vb = tp2[1], vc = tp2[2], wa = tp3[0], wb = tp3[1], wc = tp3[2];
+                asm volatile("" : "+v"(ta.x), "+v"(tb.x), "+v"(tc.x), "+v"(ua.x), "+v"(ub.x), "+v"(uc.x),
+                                  "+v"(va.x), "+v"(vb.x), "+v"(vc.x), "+v"(wa.x), "+v"(wb.x), "+v"(wc.x));
+                const float dist0 = mt_intersect(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), p, dir);
+                const float dist1 = mt_intersect(mk3(ua.x, ua.y, ua.z), mk3(ua.w, ub.x, ub.y), mk3(ub.z, ub.w, uc.x), p, dir);
+                const float dist2 = mt_intersect(mk3(va.x, va.y, va.z), mk3(va.w, vb.x, vb.y), mk3(vb.z, vb.w, vc.x), p, dir);
+                const float dist3 = mt_intersect(mk3(wa.x, wa.y, wa.z), mk3(wa.w, wb.x, wb.y), mk3(wb.z, wb.w, wc.x), p, dir);
+                if ((dist0 > RVB_EPSILON && dist0 <= mag) || (1u < count && dist1 > RVB_EPSILON && dist1 <= mag)
+                    || (2u < count && dist2 > RVB_EPSILON && dist2 <= mag) || (3u < count && dist3 > RVB_EPSILON && dist3 <= mag)) {
+                    blocked = true;
+                    break;
+                }
+                if (sp != bottom) { sp -= LANE_RAYS; ref = *sp; } else break;
+            }
+        }
+        const bool visible = !blocked;
+        const float dist = visible ? new_dist + mag : 0.0f;          // kernel.cpp:471
+        float4 o_lo = make_float4(0, 0, 0, 0), o_hi = o_lo;
+        if (visible) {
+            float4 d_lo, d_hi;                                       // diffuse coefficients
+            if (SURF_LDS) { d_lo = lds_load4(surf_lds, 4 * surface + 2); d_hi = lds_load4(surf_lds, 4 * surface + 3); }
+            else { const float4 * row = reinterpret_cast<const float4 *>(a.scene.surfaces + surface); d_lo = row[2]; d_hi = row[3]; }
+            // kernel.cpp:480-485: newVol * attenuation * diffuse * DIFF, left to right
+            o_lo.x = ((vol_lo.x * (air_attenuation(dist, a.air[0]) * 1.0f)) * d_lo.x) * diff;
+            o_lo.y = ((vol_lo.y * (air_attenuation(dist, a.air[1]) * 1.0f)) * d_lo.y) * diff;
+            o_lo.z = ((vol_lo.z * (air_attenuation(dist, a.air[2]) * 1.0f)) * d_lo.z) * diff;
+            o_lo.w = ((vol_lo.w * (air_attenuation(dist, a.air[3]) * 1.0f)) * d_lo.w) * diff;
+            o_hi.x = ((vol_hi.x * (air_attenuation(dist, a.air[4]) * 1.0f)) * d_hi.x) * diff;
+            o_hi.y = ((vol_hi.y * (air_attenuation(dist, a.air[5]) * 1.0f)) * d_hi.y) * diff;
+            o_hi.z = ((vol_hi.z * (air_attenuation(dist, a.air[6]) * 1.0f)) * d_hi.z) * diff;
+            o_hi.w = ((vol_hi.w * (air_attenuation(dist, a.air[7]) * 1.0f)) * d_hi.w) * diff;
+        }
+        const float t = seconds_per_meter() * dist;                  // kernel.cpp:489
+        store_stream(rec + 0, o_lo);
+        store_stream(rec + 1, o_hi);
+        store_stream(rec + 2, make_float4(p.x, p.y, p.z, 0.0f));
+        store_stream(rec + 3, make_float4(t, 0.0f, 0.0f, 0.0f));
+        const bool nonzero = o_lo.x != 0.0f || o_lo.y != 0.0f || o_lo.z != 0.0f || o_lo.w != 0.0f
+                          || o_hi.x != 0.0f || o_hi.y != 0.0f || o_hi.z != 0.0f || o_hi.w != 0.0f;
+        if (nonzero) {
+            if (a.npairs > 1) {
+                const volatile uint32_t * seen = a.time_range + 2u * pair;
+                if (t != 0.0f && __float_as_uint(t) < seen[0]) atomicMin(a.time_range + 2u * pair, __float_as_uint(t));
+                if (__float_as_uint(t) > seen[1]) atomicMax(a.time_range + 2u * pair + 1u, __float_as_uint(t));
+            } else {
+                if (t != 0.0f) tmin = fminf(tmin, t);
+                tmax_seen = fmaxf(tmax_seen, t);
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        tmin = fminf(tmin, __shfl_xor(tmin, off));
+        tmax_seen = fmaxf(tmax_seen, __shfl_xor(tmax_seen, off));
+    }
+    if (threadIdx.x == 0 && a.npairs <= 1) {
+        const volatile uint32_t * seen = a.time_range;
+        if (tmin != __builtin_inff() && __float_as_uint(tmin) < seen[0]) atomicMin(a.time_range + 0, __float_as_uint(tmin));
+        if (__float_as_uint(tmax_seen) > seen[1]) atomicMax(a.time_range + 1, __float_as_uint(tmax_seen));
+    }
+}
+
 }  // namespace
 
 // LDS of a quad kernel's single-wave workgroup: the traversal stack, then (optionally) the surface table, then — path kernel only — the key runs
@@ -1929,7 +2073,7 @@ void rvb_launch_images(const TraceArgs & a, hipStream_t s)
 uint32_t rvb_shadow_lanes()
 {
     static const int lanes = getenv("RVB_SHADOW_LANES") ? atoi(getenv("RVB_SHADOW_LANES")) : 2;
-    return lanes == 4 ? 4u : 2u;
+    return lanes == 4 ? 4u : (lanes == 1 ? 1u : 2u);
 }
 
 void rvb_launch_shadow(const TraceArgs & a, hipStream_t s)
@@ -1939,6 +2083,15 @@ void rvb_launch_shadow(const TraceArgs & a, hipStream_t s)
     uint64_t blocks = (total + QUADS_PER_BLOCK - 1) / QUADS_PER_BLOCK;
     static const uint64_t per_cu = getenv("RVB_SHADOW_WG_PER_CU") ? strtoull(getenv("RVB_SHADOW_WG_PER_CU"), nullptr, 10) : 256;
     if (blocks > 256u * per_cu) blocks = 256u * per_cu;     // single-wave workgroups per CU; records beyond are grid-strided
+    if (rvb_shadow_lanes() == 1) {
+        blocks = (total + LANE_RAYS - 1) / LANE_RAYS;
+        static const uint64_t lane_per_cu = getenv("RVB_SHADOW_WG_PER_CU") ? strtoull(getenv("RVB_SHADOW_WG_PER_CU"), nullptr, 10) : 128;
+        if (blocks > 256u * lane_per_cu) blocks = 256u * lane_per_cu;
+        const size_t lds = (a.stack_entries + 1u) * LANE_RAYS * sizeof(uint32_t) + (size_t) a.lds_surfaces * sizeof(rvb_surface);
+        if (a.lds_surfaces) hipLaunchKernelGGL(shadow_lane_kernel<true>, dim3((unsigned) blocks), dim3(WAVE), lds, s, a);
+        else hipLaunchKernelGGL(shadow_lane_kernel<false>, dim3((unsigned) blocks), dim3(WAVE), lds, s, a);
+        return;
+    }
     if (rvb_shadow_lanes() == 2) {
         blocks = (total + PAIRS_PER_BLOCK - 1) / PAIRS_PER_BLOCK;
         static const uint64_t pair_per_cu = getenv("RVB_SHADOW_WG_PER_CU") ? strtoull(getenv("RVB_SHADOW_WG_PER_CU"), nullptr, 10) : 256;

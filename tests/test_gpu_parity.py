@@ -131,6 +131,11 @@ def test_quad_shadow_kernel_gives_the_same_bytes(ctx):
     line = [l for l in out.stdout.splitlines() if l.startswith("CRC")][-1]
     assert "shadow_kernel" in line and "shadow_pair_kernel" not in line
     assert int(line.split()[1]) == mine
+    # ... and the one-lane-per-record form of round 4 (RVB_SHADOW_LANES=1: measured, not the default)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RVB_SHADOW_LANES="1"), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("CRC")][-1]
+    assert "shadow_lane_kernel" in line and int(line.split()[1]) == mine
 
 
 def test_own_radix_sort_gives_the_same_bytes(ctx, oracle):
