@@ -1,0 +1,99 @@
+"""The pipeline behind the C-ABI (rvb_pipeline_*, csrc/pipeline.hip) through its ctypes binding, against distributed.generate_ir on one
+context: incomplete groups, more contexts than jobs, image sources only / diffuse only, no predelay trimming, both histogram modes, the
+HRTF model with a facing per job, results taken late (the ring of pinned buffers), a pipeline re-configured between batches."""
+import numpy as np
+import pytest
+
+from parallel_reverb_raytracer_amd import dtypes, scenes
+
+pytestmark = pytest.mark.gpu
+
+SPEAKERS = ([(-1, 0, -1), (1, 0, -1)], [0.5, 0.5])
+NREFL = 24
+
+
+@pytest.fixture(scope="module")
+def rig():
+    from parallel_reverb_raytracer_amd import capi
+    scene, info = scenes.concert_hall(6000)
+    dirs = scenes.sphere_directions(9000, seed=31)
+    ctxs = [capi.Context(0) for _ in range(5)]
+    for c in ctxs:
+        c.set_scene(scene)
+        c.set_directions(dirs)
+    src, mic = scenes.source_mic_pairs(9, seed=5)
+    yield ctxs[:4], ctxs[4], [(tuple(float(x) for x in m), tuple(float(x) for x in s)) for s, m in zip(src, mic)]      # (microphone, source)
+    for c in ctxs:
+        c.close()
+
+
+def _solo(ctx, mic, src, mode, which, trim, model=None, remove_direct=False):
+    import torch
+    from parallel_reverb_raytracer_amd import distributed
+    hist, info = distributed.generate_ir(ctx, mic, src, NREFL, dtypes.AIR_COEFFICIENTS, SPEAKERS[0], SPEAKERS[1], 44100.0, trim_predelay=trim,
+                                         mode=mode, which=which, remove_direct=remove_direct, device=torch.device("cuda", 0), model=model)
+    ctx.synchronize()
+    return hist.cpu().numpy(), info
+
+
+@pytest.mark.parametrize("ncontexts,group,njobs", [(4, 0, 3), (4, 0, 9), (3, 3, 4), (1, 0, 2), (2, 1, 5)])
+def test_jobs_through_the_pipeline_equal_one_context_bit_for_bit(rig, ncontexts, group, njobs):
+    from parallel_reverb_raytracer_amd import capi
+    ctxs, solo, pairs = rig
+    pipe = capi.Pipeline(ctxs[:ncontexts], group)
+    try:
+        pipe.configure_speakers(SPEAKERS[0], SPEAKERS[1], NREFL, dtypes.AIR_COEFFICIENTS, 44100.0, True, capi.IR_EXACT)
+        for mic, src in pairs[:njobs]:
+            pipe.submit(mic, src)
+        assert pipe.pending() == njobs
+        for k, (mic, src) in enumerate(pairs[:njobs]):
+            got, info = pipe.next()
+            want, winfo = _solo(solo, mic, src, capi.IR_EXACT, capi.IR_ALL, True)
+            assert info["job"] == k and info["nbins"] == winfo["nbins"] and info["images"] == winfo["images"]
+            assert np.float32(info["predelay"]) == np.float32(winfo["predelay"])
+            assert got.shape == want.shape and np.array_equal(got, want) and got.any()
+        assert pipe.pending() == 0
+        with pytest.raises(capi.RvbError):
+            pipe.next()
+    finally:
+        pipe.close()
+
+
+def test_reconfigured_between_batches_images_only_diffuse_only_fast_mode_and_hrtf(rig):
+    from parallel_reverb_raytracer_amd import capi, distributed
+    ctxs, solo, pairs = rig
+    pipe = capi.Pipeline(ctxs)
+    try:
+        # image sources only, the direct path removed, no predelay trimming
+        pipe.configure_speakers(SPEAKERS[0], SPEAKERS[1], NREFL, dtypes.AIR_COEFFICIENTS, 44100.0, False, capi.IR_EXACT, which=capi.IR_IMAGES, remove_direct=True)
+        for mic, src in pairs[:3]:
+            pipe.submit(mic, src)
+        views = [pipe.next(copy=False) for _ in range(3)]            # taken late: three results stay valid in the ring of 8 buffers
+        for (got, info), (mic, src) in zip(views, pairs[:3]):
+            want, winfo = _solo(solo, mic, src, capi.IR_EXACT, capi.IR_IMAGES, False, remove_direct=True)
+            assert info["predelay"] == 0.0 and info["images"] == winfo["images"]
+            assert np.array_equal(np.asarray(got), want)
+        # diffuse only, float atomics: within the fast mode's tolerance of the exact histogram
+        pipe.configure_speakers(SPEAKERS[0], SPEAKERS[1], NREFL, dtypes.AIR_COEFFICIENTS, 44100.0, True, capi.IR_FAST, which=capi.IR_DIFFUSE)
+        mic, src = pairs[4]
+        pipe.submit(mic, src)
+        got, info = pipe.next()
+        want, _ = _solo(solo, mic, src, capi.IR_EXACT, capi.IR_DIFFUSE, True)
+        band_max = np.abs(want).max(axis=2, keepdims=True)
+        assert info["images"] == 0 and (np.abs(got.astype(np.float64) - want) <= 1e-5 * band_max).all() and got.any()
+        # HRTF, every job facing its source
+        table = scenes.hrtf_synthetic_table()
+        pipe.configure_hrtf(table, (0.0, 0.0, 1.0), (0.0, 1.0, 0.0), NREFL, dtypes.AIR_COEFFICIENTS, 44100.0, True, capi.IR_EXACT)
+        facings = []
+        for mic, src in pairs[5:9]:
+            d = np.array(src, np.float64) - np.array(mic, np.float64)
+            d[1] = 0.0
+            facing = tuple(float(x) for x in d / np.linalg.norm(d))
+            facings.append(facing)
+            pipe.submit(mic, src, facing, (0.0, 1.0, 0.0))
+        for (mic, src), facing in zip(pairs[5:9], facings):
+            got, info = pipe.next()
+            want, winfo = _solo(solo, mic, src, capi.IR_EXACT, capi.IR_ALL, True, model=distributed.HrtfModel(table, facing, (0.0, 1.0, 0.0)))
+            assert info["nbins"] == winfo["nbins"] and np.array_equal(got, want)
+    finally:
+        pipe.close()
