@@ -192,10 +192,16 @@ enum { RVB_IR_FAST = 0, RVB_IR_EXACT = 1 };
 
 int rvb_ir_configure_speakers(rvb_ctx * ctx, const float mic[3], const rvb_speaker * speakers, uint64_t nspeakers,
                               int which, const rvb_impulse * images, uint64_t nimages);
-int rvb_ir_configure_hrtf(rvb_ctx * ctx, const float mic[3], const float * table /* [2][360*180*8] */,
+/* table == NULL: the table of this context's previous rvb_ir_configure_hrtf call stays on the device (many listeners, one table: 4 MB
+ * uploaded once instead of per impulse response); RVB_ERR_STATE if there is none. */
+int rvb_ir_configure_hrtf(rvb_ctx * ctx, const float mic[3], const float * table /* [2][360*180*8] or NULL */,
                           const float facing[3], const float up[3],
                           int which, const rvb_impulse * images, uint64_t nimages);
 int rvb_ir_time_range(rvb_ctx * ctx, float * min_nonzero_time, float * max_time);
+/* Optional first half of rvb_ir_time_range: enqueues what the range needs on the device (the HRTF model's pass over the impulses; nothing
+ * for speakers) without waiting; the rvb_ir_time_range that follows only waits and reads.  A caller that finishes several contexts'
+ * impulse responses together calls this on all of them first (csrc/pipeline.hip). */
+int rvb_ir_time_range_begin(rvb_ctx * ctx);
 /* nbins for a given max time / predelay exactly as rayverb.cpp:57 computes MAX_SAMPLE. */
 uint64_t rvb_ir_bins(float max_time, float predelay, float sample_rate);
 int rvb_ir_accumulate(rvb_ctx * ctx, float predelay, float sample_rate, uint64_t nbins, int mode,

@@ -28,7 +28,7 @@ SYMBOLS = [
     "rvb_trace_pairs", "rvb_ir_select_pair",
     "rvb_get_diffuse", "rvb_diffuse_device", "rvb_get_direct", "rvb_get_image_candidates", "rvb_merge_images",
     "rvb_attenuate_speaker", "rvb_attenuate_speaker_device", "rvb_attenuate_hrtf", "rvb_attenuate_hrtf_device", "rvb_flatten",
-    "rvb_ir_configure_speakers", "rvb_ir_configure_hrtf", "rvb_ir_time_range", "rvb_ir_bins", "rvb_ir_accumulate", "rvb_ir_accumulate_export", "rvb_ir_exact_prepare", "rvb_ir_exact_fold", "rvb_record_event",
+    "rvb_ir_configure_speakers", "rvb_ir_configure_hrtf", "rvb_ir_time_range", "rvb_ir_time_range_begin", "rvb_ir_bins", "rvb_ir_accumulate", "rvb_ir_accumulate_export", "rvb_ir_exact_prepare", "rvb_ir_exact_fold", "rvb_record_event",
     "rvb_ir_download", "rvb_last_timings", "rvb_debug_stamps", "rvb_executed_bounces",
     "rvb_device_alloc", "rvb_device_free", "rvb_copy_to_host", "rvb_copy_to_device", "rvb_fix_predelay_device", "rvb_flatten_device",
     "rvb_host_alloc", "rvb_host_free", "rvb_copy_to_pinned_host_async", "rvb_synchronize_exports",

@@ -66,6 +66,8 @@ struct rvb_ctx {
     uint64_t nrays = 0;
     uint32_t concurrent_traces = 1;             // rvb_set_concurrent_traces
     uint32_t path_lanes = 0;                    // rvb_set_path_lanes: 0 = chosen per launch (rvb_path_lanes_for)
+    bool range_pending = false;                 // rvb_ir_time_range_begin has enqueued the HRTF time-range pass of the current configuration
+    int hrtf_table_ears = 0;                    // ears of the HRTF table on the device: 2 after rvb_ir_configure_hrtf, 1 after the one-ear attenuate calls
     bool traced = false;
     uint64_t nreflections = 0;
     float mic[3] = {0, 0, 0};
@@ -86,6 +88,7 @@ struct rvb_ctx {
     // are asynchronous and the host waits once.
     unsigned char * small_host = nullptr;       // [kSmallBytes]
     rvb_image_candidate * first_candidates = nullptr;   // [kFirstCandidates], behind small_host in the same block
+    uint32_t * range_host = nullptr;            // [2] behind them: where the HRTF time-range pass lands (rvb_ir_time_range_begin)
     bool small_valid = false;
     bool stamps_cleared = false;
     std::vector<Timing> timings;
@@ -233,13 +236,14 @@ int rvb_create(rvb_ctx ** out, int device, unsigned flags)
         (e = hipEventCreateWithFlags(&ctx->prep_done, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->group_done, hipEventDisableTiming)) != hipSuccess ||
         (e = ctx->small.ensure(kSmallBytes)) != hipSuccess ||
-        (e = hipHostMalloc(reinterpret_cast<void **>(&ctx->small_host), kSmallBytes + kFirstCandidates * sizeof(rvb_image_candidate), hipHostMallocDefault)) != hipSuccess) {
+        (e = hipHostMalloc(reinterpret_cast<void **>(&ctx->small_host), kSmallBytes + kFirstCandidates * sizeof(rvb_image_candidate) + 16, hipHostMallocDefault)) != hipSuccess) {
         std::string what = std::string("rvb_create: ") + hipGetErrorString(e);
         delete ctx;
         return fail(nullptr, RVB_ERR_HIP, what);
     }
-    std::memset(ctx->small_host, 0, kSmallBytes + kFirstCandidates * sizeof(rvb_image_candidate));
+    std::memset(ctx->small_host, 0, kSmallBytes + kFirstCandidates * sizeof(rvb_image_candidate) + 16);
     ctx->first_candidates = reinterpret_cast<rvb_image_candidate *>(ctx->small_host + kSmallBytes);
+    ctx->range_host = reinterpret_cast<uint32_t *>(ctx->small_host + kSmallBytes + kFirstCandidates * sizeof(rvb_image_candidate));
     *out = ctx;
     return RVB_OK;
 }
@@ -939,6 +943,7 @@ int rvb_attenuate_hrtf(rvb_ctx * ctx, const float mic[3], const rvb_impulse * in
     std::memcpy(both.data() + (size_t) channel * 360 * 180 * 8, table, (size_t) 360 * 180 * 8 * sizeof(float));
     int rc = upload_hrtf_table(ctx, both.data(), 2);
     if (rc != RVB_OK) return rc;
+    ctx->hrtf_table_ears = 1;                 // (one ear's table in its slot: not what rvb_ir_configure_hrtf(table == NULL) may reuse)
     AttenuationModel m;
     m.hrtf = 1;
     m.nchannels = 2;
@@ -961,6 +966,7 @@ int rvb_attenuate_hrtf_device(rvb_ctx * ctx, const float mic[3], const void * d_
     std::memcpy(both.data() + (size_t) channel * 360 * 180 * 8, table, (size_t) 360 * 180 * 8 * sizeof(float));
     int rc = upload_hrtf_table(ctx, both.data(), 2);
     if (rc != RVB_OK) return rc;
+    ctx->hrtf_table_ears = 1;                 // (one ear's table in its slot: not what rvb_ir_configure_hrtf(table == NULL) may reuse)
     AttenuationModel m;
     m.hrtf = 1;
     m.nchannels = 2;
@@ -1312,6 +1318,7 @@ static int configure_common(rvb_ctx * ctx, int which, const rvb_impulse * images
     ctx->which = which;
     ctx->ir_configured = true;
     ctx->exact.valid = false;
+    ctx->range_pending = false;
     return RVB_OK;
 }
 
@@ -1338,11 +1345,19 @@ int rvb_ir_configure_hrtf(rvb_ctx * ctx, const float mic[3], const float * table
                           int which, const rvb_impulse * images, uint64_t nimages)
 {
     if (!ctx) return RVB_ERR_INVALID;
-    if (!mic || !table || !facing || !up) return fail(ctx, RVB_ERR_INVALID, "rvb_ir_configure_hrtf: null argument");
+    if (!mic || !facing || !up) return fail(ctx, RVB_ERR_INVALID, "rvb_ir_configure_hrtf: null argument");
     RVB_BIND(ctx);
-    RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    int rc = upload_hrtf_table(ctx, table, 2);
-    if (rc != RVB_OK) return rc;
+    if (table) {
+        // (the table on the device may still be read by kernels enqueued under the previous configuration)
+        RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        int rc = upload_hrtf_table(ctx, table, 2);
+        if (rc != RVB_OK) return rc;
+        ctx->hrtf_table_ears = 2;
+    } else if (ctx->hrtf_table_ears != 2) {
+        // table == NULL: the two-ear table of the previous rvb_ir_configure_hrtf on this context stays (a caller that configures many
+        // listeners with one table — the pipeline — uploads its 4 MB once, not per impulse response)
+        return fail(ctx, RVB_ERR_STATE, "rvb_ir_configure_hrtf: table == NULL needs an earlier call with a table on this context");
+    }
     AttenuationModel m;
     m.hrtf = 1;
     m.nchannels = 2;
@@ -1350,6 +1365,36 @@ int rvb_ir_configure_hrtf(rvb_ctx * ctx, const float mic[3], const float * table
     for (int i = 0; i < 3; ++i) { m.mic[i] = mic[i]; m.facing[i] = facing[i]; m.up[i] = up[i]; }
     ctx->model = m;
     return configure_common(ctx, which, images, nimages);
+}
+
+// HRTF model: the attenuated time of an impulse differs per ear (kernel.cpp:616-622), so the range needs a pass over the impulses; the
+// pass and the copy of its two words to pinned host memory are ENQUEUED here and waited for in rvb_ir_time_range — a caller with several
+// contexts enqueues all of them (rvb_ir_time_range_begin) before it waits for the first.
+static int time_range_enqueue(rvb_ctx * ctx)
+{
+    uint32_t * range = reinterpret_cast<uint32_t *>(ctx->small.as<char>() + kSmallRange);
+    RVB_HIP(ctx, hipMemsetAsync(range, 0xFF, 4, ctx->stream));
+    RVB_HIP(ctx, hipMemsetAsync(range + 1, 0, 4, ctx->stream));
+    ctx->reset_timings();
+    ctx->begin_timing("time_range_kernel");
+    if (ctx->which & RVB_IR_DIFFUSE)
+        rvb_launch_time_range(ctx->model, ir_diffuse(ctx), ctx->nrays * ctx->nreflections, range, ctx->stream);
+    if (ctx->which & RVB_IR_IMAGES)
+        rvb_launch_time_range(ctx->model, ctx->images.as<rvb_impulse>(), ctx->nimages, range, ctx->stream);
+    ctx->end_timing();
+    RVB_HIP(ctx, hipGetLastError());
+    RVB_HIP(ctx, hipMemcpyAsync(ctx->range_host, range, 8, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->range_pending = true;
+    return RVB_OK;
+}
+
+int rvb_ir_time_range_begin(rvb_ctx * ctx)
+{
+    if (!ctx) return RVB_ERR_INVALID;
+    if (!ctx->ir_configured) return fail(ctx, RVB_ERR_STATE, "rvb_ir_time_range_begin: rvb_ir_configure_* first");
+    RVB_BIND(ctx);
+    if (!ctx->model.hrtf) return RVB_OK;          // speakers: the range came with the trace (reduced inside the shadow kernel)
+    return time_range_enqueue(ctx);
 }
 
 int rvb_ir_time_range(rvb_ctx * ctx, float * min_nonzero_time, float * max_time)
@@ -1384,20 +1429,14 @@ int rvb_ir_time_range(rvb_ctx * ctx, float * min_nonzero_time, float * max_time)
         if (max_time) *max_time = hi;
         return RVB_OK;
     }
-    uint32_t * range = reinterpret_cast<uint32_t *>(ctx->small.as<char>() + kSmallRange);
-    RVB_HIP(ctx, hipMemsetAsync(range, 0xFF, 4, ctx->stream));
-    RVB_HIP(ctx, hipMemsetAsync(range + 1, 0, 4, ctx->stream));
-    ctx->reset_timings();
-    ctx->begin_timing("time_range_kernel");
-    if (ctx->which & RVB_IR_DIFFUSE)
-        rvb_launch_time_range(ctx->model, ir_diffuse(ctx), ctx->nrays * ctx->nreflections, range, ctx->stream);
-    if (ctx->which & RVB_IR_IMAGES)
-        rvb_launch_time_range(ctx->model, ctx->images.as<rvb_impulse>(), ctx->nimages, range, ctx->stream);
-    ctx->end_timing();
-    RVB_HIP(ctx, hipGetLastError());
-    uint32_t got[2];
-    RVB_HIP(ctx, hipMemcpyAsync(got, range, sizeof(got), hipMemcpyDeviceToHost, ctx->stream));
+    if (!ctx->range_pending) {
+        const int rc = time_range_enqueue(ctx);
+        if (rc != RVB_OK) return rc;
+    }
+    ctx->range_pending = false;
     RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    uint32_t got[2];
+    std::memcpy(got, ctx->range_host, sizeof(got));
     float lo = 0.0f, hi;
     if (got[0] != 0xFFFFFFFFu) std::memcpy(&lo, &got[0], 4);
     std::memcpy(&hi, &got[1], 4);

@@ -36,6 +36,7 @@ struct Job {
 
 struct Slot {                                 // per context
     rvb_ctx * ctx = nullptr;
+    bool has_table = false;                   // the pipeline's HRTF table is on this context's device (uploaded with its first HRTF job)
     float * hist = nullptr;                   // device [nchannels][8][nbins]
     size_t hist_cap = 0;
     hipEvent_t zeroed = nullptr;
@@ -127,9 +128,10 @@ int begin_upto(rvb_pipeline * p, uint64_t limit)
     return RVB_OK;
 }
 
-// image-source merge, configuration, time range and the binning + export of one traced job: everything is ENQUEUED, the only host
-// wait is the one for the trace's small result block (image-source candidates, time range)
-int stage_job(rvb_pipeline * p, Job & j)
+// Staging of a traced job in two phases, so that a group's jobs overlap their device work: (1) image-source merge and configuration — the
+// only host wait is the one for the trace's small result block (image-source candidates, time range of the speaker model) — and the HRTF
+// model's time-range pass ENQUEUED; (2) the time range read, the histogram sized and zeroed, binning + export enqueued.
+int stage_configure(rvb_pipeline * p, Job & j)
 {
     Slot & s = p->slots[(size_t) (j.id % p->slots.size())];
     rvb_ctx * ctx = s.ctx;
@@ -147,14 +149,27 @@ int stage_job(rvb_pipeline * p, Job & j)
         if (nimages && (rc = rvb_merge_images(p->candidates.data(), ncand, &direct, p->remove_direct, p->images.data(), nimages, &nimages)) != RVB_OK)
             return pfail(p, rc, "rvb_pipeline: rvb_merge_images");
     }
-    if (p->hrtf) rc = rvb_ir_configure_hrtf(ctx, j.mic, p->table.data(), j.facing, j.up, p->which, p->images.data(), nimages);
+    if (p->hrtf) {
+        // (the table goes up with a context's first job only: rvb_ir_configure_hrtf keeps it for table == NULL)
+        rc = rvb_ir_configure_hrtf(ctx, j.mic, s.has_table ? nullptr : p->table.data(), j.facing, j.up, p->which, p->images.data(), nimages);
+        s.has_table = rc == RVB_OK;
+    }
     else rc = rvb_ir_configure_speakers(ctx, j.mic, p->speakers.data(), p->speakers.size(), p->which, p->images.data(), nimages);
     if (rc != RVB_OK) return cfail(p, rc, ctx, "rvb_pipeline: configure");
+    j.nimages = nimages;
+    if ((rc = rvb_ir_time_range_begin(ctx)) != RVB_OK) return cfail(p, rc, ctx, "rvb_pipeline: time range");
+    return RVB_OK;
+}
+
+int stage_bin(rvb_pipeline * p, Job & j)
+{
+    Slot & s = p->slots[(size_t) (j.id % p->slots.size())];
+    rvb_ctx * ctx = s.ctx;
     float lo = 0.0f, hi = 0.0f;
-    if ((rc = rvb_ir_time_range(ctx, &lo, &hi)) != RVB_OK) return cfail(p, rc, ctx, "rvb_pipeline: time range");
+    int rc = rvb_ir_time_range(ctx, &lo, &hi);
+    if (rc != RVB_OK) return cfail(p, rc, ctx, "rvb_pipeline: time range");
     j.predelay = p->trim_predelay ? lo : 0.0f;
     j.max_time = hi;
-    j.nimages = nimages;
     j.nbins = rvb_ir_bins(hi, j.predelay, p->sample_rate);
     const uint64_t nch = p->hrtf ? 2 : p->speakers.size();
     const size_t bytes = (size_t) j.nbins * nch * 8 * sizeof(float);
@@ -273,6 +288,7 @@ int rvb_pipeline_configure_hrtf(rvb_pipeline * p, const float * table, const flo
     if (rc != RVB_OK) return rc;
     p->hrtf = true;
     p->table.assign(table, table + (size_t) 2 * 360 * 180 * 8);
+    for (Slot & s : p->slots) s.has_table = false;
     std::memcpy(p->facing, facing, sizeof(p->facing));
     std::memcpy(p->up, up, sizeof(p->up));
     return RVB_OK;
@@ -318,10 +334,10 @@ int rvb_pipeline_next(rvb_pipeline * p, rvb_pipeline_result * out)
     if (!j.staged) {
         // the binning stages of all (begun) jobs of this group, before the host waits for any of them
         const uint64_t last = std::min(group_first + p->group, p->begun_upto);
-        for (uint64_t id = j.id; id < last; ++id) {
-            Job & k = job_at(p, id);
-            if (!k.staged && (rc = stage_job(p, k)) != RVB_OK) return rc;
-        }
+        for (uint64_t id = j.id; id < last; ++id)
+            if ((rc = stage_configure(p, job_at(p, id))) != RVB_OK) return rc;
+        for (uint64_t id = j.id; id < last; ++id)
+            if ((rc = stage_bin(p, job_at(p, id))) != RVB_OK) return rc;
         // ... then for their binning (not for their histograms' way to the host): with it done, the group's contexts take the traces of
         // the group after next — enqueued before this call waits for the link, so the copy runs beside them
         for (uint64_t id = j.id; id < last; ++id) {

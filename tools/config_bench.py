@@ -120,16 +120,72 @@ def pairs_pipelined(scene, src, mic, nrays, nrefl, npairs):
     return out
 
 
+def native_pipeline(name, scene, jobs, nrays, nrefl, hrtf, contexts=4, repeats=3):
+    """The configuration's impulse responses back to back through the pipeline behind the C-ABI (rvb_pipeline_*, csrc/pipeline.hip):
+    jobs = [(mic, source)] (HRTF: every listener faces its source), each `repeats` times; ms per impulse response with the histogram
+    in the pipeline's pinned ring."""
+    dirs = torch.from_numpy(np.ascontiguousarray(scenes.sphere_directions(nrays, seed=1))).cuda()
+    torch.cuda.synchronize()
+    ctxs = []
+    for _ in range(contexts):
+        c = capi.Context(0)
+        c.set_scene(scene)
+        c.set_directions_device(dirs.data_ptr(), nrays)
+        ctxs.append(c)
+    pipe = capi.Pipeline(ctxs)
+    if hrtf:
+        pipe.configure_hrtf(scenes.hrtf_synthetic_table(), (0, 0, 1), (0, 1, 0), nrefl, dtypes.AIR_COEFFICIENTS, 44100.0, True, MODE)
+    else:
+        pipe.configure_speakers([(-1, 0, -1), (1, 0, -1)], [0.5, 0.5], nrefl, dtypes.AIR_COEFFICIENTS, 44100.0, True, MODE)
+
+    def run(todo):
+        sent = taken = 0
+        nbins = 0
+        while taken < len(todo):
+            while sent < len(todo) and pipe.pending() < 2 * contexts:
+                mic, src = todo[sent]
+                if hrtf:
+                    f = np.asarray(src, np.float64) - np.asarray(mic, np.float64)
+                    pipe.submit(mic, src, tuple(f / np.linalg.norm(f)), (0.0, 1.0, 0.0))
+                else:
+                    pipe.submit(mic, src)
+                sent += 1
+            _, info = pipe.next(copy=False)
+            nbins = info["nbins"]
+            taken += 1
+        return nbins
+    run(jobs[:contexts])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nbins = run(jobs * repeats)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / (len(jobs) * repeats)
+    pipe.close()
+    for c in ctxs:
+        c.close()
+    return {"config": name + " — native pipeline, %d contexts" % contexts, "triangles": int(scene[0].shape[0]), "rays": nrays, "reflections": nrefl,
+            "model": "hrtf" if hrtf else "speakers", "ms_per_ir": ms, "ray_bounces_per_sec": nrays * nrefl / (ms * 1e-3), "nbins_last": int(nbins), "kernel_ms": {}}
+
+
 def main():
     results = []
+    # round 4: the configurations through the pipeline behind the C-ABI, each in a process state of its own as far as this tool goes
+    # (measured first: a leg that runs after the one-context legs below reads 10-20 % slower on the same box)
+    hall, _ = scenes.concert_hall(30000)
+    src, mic = scenes.source_mic_pairs(64, seed=0)
+    for nctx in (4, 2):
+        results.append(native_pipeline("C5 per-GPU share: 8 pairs, 100k rays x 128, HRTF", hall, [(tuple(map(float, mic[p])), tuple(map(float, src[p]))) for p in range(8)],
+                                       100000, 128, True, contexts=nctx))
+    scene, info = scenes.cathedral(75000)
+    results.append(native_pipeline("C3 per-GPU share: 125k rays x 128", scene, [(info["mic"], info["source"])] * 8, 125000, 128, False))
+    scene, info = scenes.atrium(262000)
+    results.append(native_pipeline("C4: atrium stand-in, 100k rays x 256", scene, [(info["mic"], info["source"])] * 6, 100000, 256, False, repeats=2))
+    results.append(pairs_pipelined(hall, src, mic, 100000, 128, 8))
     scene, info = scenes.cathedral(75000)
     results.append(run("C3 per-GPU share: cathedral stand-in, 125k rays x 128", scene, info["mic"], info["source"], 125000, 128, "speakers"))
     scene, info = scenes.atrium(262000)
     results.append(run("C4: atrium stand-in, 100k rays x 256", scene, info["mic"], info["source"], 100000, 256, "speakers"))
-    scene, _ = scenes.concert_hall(30000)
-    src, mic = scenes.source_mic_pairs(64, seed=0)
-    results.append(run("C5 one of 64 pairs: concert-hall stand-in, 100k rays x 128, HRTF", scene, mic[0], src[0], 100000, 128, "hrtf"))
-    results.append(pairs_pipelined(scene, src, mic, 100000, 128, 8))
+    results.append(run("C5 one of 64 pairs: concert-hall stand-in, 100k rays x 128, HRTF", hall, mic[0], src[0], 100000, 128, "hrtf"))
     print(json.dumps(results, indent=1))
 
 
