@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <string>
@@ -340,6 +341,10 @@ int rvb_pipeline_next(rvb_pipeline * p, rvb_pipeline_result * out)
             if ((rc = stage_bin(p, job_at(p, id))) != RVB_OK) return rc;
         // ... then for their binning (not for their histograms' way to the host): with it done, the group's contexts take the traces of
         // the group after next — enqueued before this call waits for the link, so the copy runs beside them
+        // (measured: enqueuing those traces in stream order behind the binning, BEFORE this wait — RVB_PIPELINE_EARLY_TRACES=1 — costs 4.45 -> 5.6 ms per
+        // IR at workload C2: a third group's path kernel then competes with this group's binning for the SIMDs)
+        static const bool early = getenv("RVB_PIPELINE_EARLY_TRACES") && getenv("RVB_PIPELINE_EARLY_TRACES")[0] == '1';
+        if (early && (rc = begin_upto(p, std::min(group_first + p->group + n, p->submitted / p->group * p->group))) != RVB_OK) return rc;
         for (uint64_t id = j.id; id < last; ++id) {
             rvb_ctx * c = p->slots[(size_t) (id % n)].ctx;
             if ((rc = rvb_synchronize(c)) != RVB_OK) return cfail(p, rc, c, "rvb_pipeline_next: wait");
