@@ -349,6 +349,7 @@ int rvb_pipeline_next(rvb_pipeline * p, rvb_pipeline_result * out)
             rvb_ctx * c = p->slots[(size_t) (id % n)].ctx;
             if ((rc = rvb_synchronize(c)) != RVB_OK) return cfail(p, rc, c, "rvb_pipeline_next: wait");
         }
+        // (and enqueuing them LATER costs as well: a host delay of 100 / 300 / 600 / 1000 us here: 4.45 -> 4.53 / 4.57 / 4.69 / 4.96 ms per IR)
         if ((rc = begin_upto(p, std::min(group_first + p->group + n, p->submitted / p->group * p->group))) != RVB_OK) return rc;
     }
     rvb_ctx * ctx = p->slots[(size_t) (j.id % n)].ctx;
