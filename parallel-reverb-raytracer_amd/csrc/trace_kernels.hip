@@ -1006,6 +1006,9 @@ template <bool SURF_LDS>
 __device__ __forceinline__ void path_pair_body(const TraceArgs & a, const uint32_t block)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t stack_lds[];   // [stack_entries][PAIRS_PER_BLOCK]
+#if RVB_PATH_PRIO
+    __builtin_amdgcn_s_setprio(RVB_PATH_PRIO);
+#endif
     const uint32_t q = threadIdx.x >> 1;
     const uint64_t ray = (uint64_t) block * PAIRS_PER_BLOCK + q;
     const lds_float4_ptr surf_lds = stage_surfaces(a, stack_lds + a.stack_entries * PAIRS_PER_BLOCK);
@@ -1689,6 +1692,12 @@ struct ShadowJob {
 #ifndef RVB_SHADOW_PAIR_WAVES
 #define RVB_SHADOW_PAIR_WAVES 5
 #endif
+#ifndef RVB_SHADOW_PRIO
+#define RVB_SHADOW_PRIO 0
+#endif
+#ifndef RVB_PATH_PRIO
+#define RVB_PATH_PRIO 0
+#endif
 #ifndef RVB_SHADOW_WAVES
 #define RVB_SHADOW_WAVES 8     // 64 VGPRs (8 waves/SIMD): 1.845 -> 1.807 ms against 7
 #endif
@@ -1741,6 +1750,9 @@ template <bool SURF_LDS>
 __global__ __launch_bounds__(WAVE, RVB_SHADOW_PAIR_WAVES) void shadow_pair_kernel(TraceArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t stack_lds[];   // [stack_entries][PAIRS_PER_BLOCK]
+#if RVB_SHADOW_PRIO
+    __builtin_amdgcn_s_setprio(RVB_SHADOW_PRIO);      // experiment: the shadow waves win the issue arbitration against resident path waves of the other group
+#endif
     const uint32_t h = threadIdx.x & 1u;
     const uint32_t q = threadIdx.x >> 1;
     uint32_t * stack = stack_lds + q;
