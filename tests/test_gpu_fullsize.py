@@ -195,6 +195,15 @@ def check_every_ray_against_gpu_brute_force(ctx, oracle, gpu_oracle, scene, mic,
         assert ctx.get_image_candidates().tobytes() == cands.tobytes()
     finally:
         ctx.set_concurrent_traces(1)
+    # ... the one-lane-per-ray kernel of round 4 (measured, not chosen by any launch): the same bytes again
+    ctx.set_path_lanes(1)
+    try:
+        ctx.raytrace(mic, src, dirs, nrefl, AIR_COEFFICIENTS)
+        assert "path_lane_kernel" in dict(ctx.last_timings())
+        assert _crc(ctx.get_raw_diffuse()) == _crc(got), "the one-lane path kernel disagrees"
+        assert ctx.get_image_candidates().tobytes() == cands.tobytes()
+    finally:
+        ctx.set_path_lanes(0)
     # ... and the kernel the bench pipeline times: the traces of TWO contexts in ONE launch (rvb_trace_group ->
     # path_pair_group_kernel), same scene, rays, source and microphone on both, as distributed.IrPipeline issues them
     group_checked = False
