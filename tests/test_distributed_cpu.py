@@ -111,6 +111,23 @@ def test_two_rank_chained_exact_mode_with_the_hrtf_model_and_three_blocks(tmp_pa
     assert np.array_equal(two[0]["hist"], one["hist"]) and np.array_equal(two[1]["hist"], one["hist"]) and one["hist"].any()
 
 
+def test_four_rank_chain_in_five_blocks_and_all_reduce(tmp_path, oracle):
+    """More ranks than blocks in flight: four ranks, the histogram in five bin-range blocks — bit-equal to one process on every rank;
+    the same four ranks with the all-reduce of their own serial sums: equal on every rank, within the stated tolerance of one process."""
+    import torch.multiprocessing as mp
+    total_rays, nrefl = 96, 10
+    _worker(0, 1, 0, str(tmp_path), total_rays, nrefl)
+    one = np.load(os.path.join(str(tmp_path), "rank0_of1.npz"))
+    mp.spawn(_worker, args=(4, _free_port(), str(tmp_path), total_rays, nrefl, None, True, False, 5), nprocs=4, join=True)
+    chain = [np.load(os.path.join(str(tmp_path), "rank%d_of4_chain.npz" % r)) for r in range(4)]
+    assert all(np.array_equal(c["hist"], one["hist"]) for c in chain) and one["hist"].any()
+    mp.spawn(_worker, args=(4, _free_port(), str(tmp_path), total_rays, nrefl), nprocs=4, join=True)
+    summed = [np.load(os.path.join(str(tmp_path), "rank%d_of4.npz" % r)) for r in range(4)]
+    assert all(np.array_equal(c["hist"], summed[0]["hist"]) for c in summed)
+    band_max = np.abs(one["hist"]).max(axis=2, keepdims=True)
+    assert (np.abs(summed[0]["hist"].astype(np.float64) - one["hist"]) <= 1e-5 * band_max).all()
+
+
 def test_candidate_exchange_overflow_round(tmp_path, oracle):
     """A shard with more image-source candidates than the first all-gather carries triggers exactly one more
     round; the result is the one of the roomy exchange."""
