@@ -2063,6 +2063,9 @@ void rvb_launch_path_group(const TraceArgs * traces, uint32_t count, hipStream_t
     for (uint32_t k = count; k < RVB_MAX_GROUP; ++k) g.trace[k] = traces[0];
     size_t lds = 0;                          // (the largest of the traces', should a caller ever group traces whose layouts differ in size)
     for (uint32_t k = 0; k < count; ++k) lds = std::max(lds, a.path_lanes == 1 ? rvb_lane_lds_bytes(traces[k]) : rvb_pair_lds_bytes(traces[k]));
+    // measurement: an LDS request per workgroup that caps the path waves per CU (160 KiB / bytes), leaving wave slots and registers to other kernels
+    static const size_t lds_floor = getenv("RVB_PATH_LDS_BYTES") ? strtoull(getenv("RVB_PATH_LDS_BYTES"), nullptr, 10) : 0;
+    lds = std::max(lds, lds_floor);
     if (a.path_lanes == 1) {
         if (a.lds_surfaces) hipLaunchKernelGGL(path_lane_group_kernel<true>, dim3(blocks), dim3(WAVE), lds, s, g);
         else hipLaunchKernelGGL(path_lane_group_kernel<false>, dim3(blocks), dim3(WAVE), lds, s, g);
