@@ -331,10 +331,13 @@ class Context:
         self.nchannels = sp.shape[0]
 
     def ir_configure_hrtf(self, mic, table, facing, up, which=IR_ALL, images=None):
-        t = np.ascontiguousarray(table, dtype=np.float32).reshape(-1)
-        assert t.shape[0] == 2 * 360 * 180 * 8
+        """table: [2][360][180][8] floats, or None = the table of this context's previous ir_configure_hrtf stays on the device (many
+        listeners, one table: the 4 MB go up once)."""
+        if table is not None:
+            t = np.ascontiguousarray(table, dtype=np.float32).reshape(-1)
+            assert t.shape[0] == 2 * 360 * 180 * 8
         img = np.ascontiguousarray(images, dtype=IMPULSE) if images is not None else np.zeros(0, dtype=IMPULSE)
-        self._check(self.lib.rvb_ir_configure_hrtf(self.handle, _f3(mic), _ptr(t), _f3(facing), _f3(up), ctypes.c_int(which),
+        self._check(self.lib.rvb_ir_configure_hrtf(self.handle, _f3(mic), _ptr(t) if table is not None else None, _f3(facing), _f3(up), ctypes.c_int(which),
                                                    _ptr(img), _u64(img.shape[0])))
         self.nchannels = 2
 

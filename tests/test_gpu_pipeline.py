@@ -97,3 +97,31 @@ def test_reconfigured_between_batches_images_only_diffuse_only_fast_mode_and_hrt
             assert info["nbins"] == winfo["nbins"] and np.array_equal(got, want)
     finally:
         pipe.close()
+
+
+def test_hrtf_table_stays_on_the_device_for_table_none(rig):
+    """rvb_ir_configure_hrtf(table = NULL): the previous call's table stays (what the pipeline does from a context's second job on); a
+    context that never had one refuses; a one-ear attenuate call in between voids it."""
+    from parallel_reverb_raytracer_amd import capi
+    ctxs, solo, pairs = rig
+    table = scenes.hrtf_synthetic_table()
+    mic, src = pairs[0]
+    ctx = capi.Context(0)
+    try:
+        ctx.set_scene(scenes.concert_hall(6000)[0])
+        ctx.raytrace(mic, src, scenes.sphere_directions(2000, seed=3), 12, dtypes.AIR_COEFFICIENTS)
+        with pytest.raises(capi.RvbError):
+            ctx.ir_configure_hrtf(mic, None, (0.0, 0.0, 1.0), (0.0, 1.0, 0.0))
+        ctx.ir_configure_hrtf(mic, table, (0.0, 0.0, 1.0), (0.0, 1.0, 0.0))
+        want = ctx.ir_download(True, 44100.0, capi.IR_EXACT)
+        ctx.ir_configure_hrtf(mic, None, (0.0, 0.0, 1.0), (0.0, 1.0, 0.0))
+        assert np.array_equal(ctx.ir_download(True, 44100.0, capi.IR_EXACT), want) and want.any()
+        ctx.ir_configure_hrtf(mic, None, (1.0, 0.0, 0.0), (0.0, 1.0, 0.0))              # another orientation, the same table
+        turned = ctx.ir_download(True, 44100.0, capi.IR_EXACT)
+        ctx.ir_configure_hrtf(mic, table, (1.0, 0.0, 0.0), (0.0, 1.0, 0.0))
+        assert np.array_equal(ctx.ir_download(True, 44100.0, capi.IR_EXACT), turned) and not np.array_equal(turned, want)
+        ctx.attenuate_hrtf(mic, ctx.get_raw_diffuse()[:8], table[0], (0.0, 0.0, 1.0), (0.0, 1.0, 0.0), 0)      # one ear's table takes the device image
+        with pytest.raises(capi.RvbError):
+            ctx.ir_configure_hrtf(mic, None, (0.0, 0.0, 1.0), (0.0, 1.0, 0.0))
+    finally:
+        ctx.close()
