@@ -86,6 +86,7 @@ struct Hit { float t; uint32_t tri; };
 #define RVB_STREAM_STORE 0
 #endif
 typedef float nt_float4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) uint32_t * lds_u32_ptr;
 typedef __attribute__((address_space(3))) const nt_float4 * lds_float4_ptr;  // keeps ds_read: a generic pointer would load flat
 __device__ __forceinline__ void store_stream(float4 * p, const float4 v)
 {
@@ -521,6 +522,25 @@ __device__ __forceinline__ void traverse_jobs_vote(const SceneDev & sc, uint32_t
 #define RVB_PAIR_SELECT 1          // bit 0: path_pair_kernel, bit 1: shadow_pair_kernel use slab_select (near / far plane by the direction's sign)
                                    // instead of slab (min / max).  Measured at C2: path pairs 3.92 -> 3.80 ms, shadow pairs 1.28 -> 1.34 ms
 #endif
+// RVB_PAIR_PUSH_COUNTS = 1 (round 4): the node step of traverse_pairs_vote written for ISSUE COST.  In the pipeline (traces of the
+// next group beside the binning of this one) the SIMDs issue vector instructions three quarters of the time, and the node step is two
+// thirds of the path kernel's instructions; tools/inst_probe.hip measures two classes of them on gfx950 — v_fma / v_add / v_mul_f32,
+// v_mov, two-operand integer add / and / or / xor / right shift and v_bitop3 issue at the full rate, everything else (comparisons,
+// selects, min / max, DPP, v_perm, v_fma_mix, three-operand integer forms) at 0.6 of it (profiles/r04b_inst_probe.log).  The step now:
+//   - pushes from COUNTS: a lane keeps the children whose key is not the pair's minimum, the second lane's entries go on top of the
+//     first lane's, so one two-bit count crosses the pair (one DPP move) instead of the four-bit hit mask and its population counts;
+//   - keys of the UNCLAMPED entry distance, compared as signed integers (no max(t, 0) per child; tools/travforms.cpp replays the same
+//     number of node visits), built with one v_bitop3_b32;
+//   - the winner's reference as (mine | theirs) with 0 in the lane that does not own it;
+//   - the culling distance is state (changes in leaf steps, five times rarer than node steps); the stack pointer is an LDS byte address.
+// 75 -> 57 vector instructions, 118 -> 91 issue units per node step (tools/isa_mix.py); same visits, same records, same bytes.
+// Measured (profiles/r04_push_counts_n1.txt): pipeline 4.47-4.50 -> 4.37-4.40 ms per impulse response with the kernel capped at 80
+// VGPRs (RVB_PAIR_WAVES = 6); uncapped it takes 84, loses a wave per SIMD to the kernels beside it and the pipeline is 8 % SLOWER
+// (4.82-4.87 ms) — the register count of the path kernel matters more than its instruction count.  Alone (one trace of 100 k rays,
+// bound by the latency of its chains) the kernel takes 3.49 ms either way.
+#ifndef RVB_PAIR_PUSH_COUNTS
+#define RVB_PAIR_PUSH_COUNTS 1
+#endif
 #define RVB_PAIR_SLAB(SEL, n, tn, skip) ((SEL) ? slab_select(n, ix, iy, iz, oix, oiy, oiz, selx, sely, selz, limit, neg_cull, skip, tn) \
                                                : slab(n, ix, iy, iz, oix, oiy, oiz, limit, neg_cull, skip, tn))
 template <class Job>
@@ -529,25 +549,52 @@ __device__ __forceinline__ void traverse_pairs_vote(const SceneDev & sc, uint32_
 {
     const uint32_t IDLE = 0xFFFFFFFEu;
     const uint32_t h = threadIdx.x & 1u;
-    const uint32_t c0 = 2u * h, c1 = c0 + 1u;                              // the children this lane owns
+    uint32_t c0 = 2u * h, c1 = c0 + 1u;                                    // the children this lane owns
+    asm volatile("" : "+v"(c0), "+v"(c1));                                 // lane constants that stay in their registers (else recomputed in every node step)
+#if !RVB_PAIR_PUSH_COUNTS
     const uint32_t bit0 = 1u << c0, bit1 = 2u << c0, lt0 = bit0 - 1u, lt1 = bit1 - 1u;
+#endif
     const char * node_base = reinterpret_cast<const char *>(sc.nodes);
     const char * tri_base = reinterpret_cast<const char *>(sc.tris);
-    const uint32_t child_off = 32u * h;
+    uint32_t child_off = 32u * h;
+    asm volatile("" : "+v"(child_off));
+    uint32_t clear2 = ~3u;
+    asm volatile("" : "+v"(clear2));
     const float neg_cull = -sc.cull_abs, cull_scale = 1.0f + sc.cull_rel;
     const unsigned long long NO_HIT_KEY = (0x7F800000ull << 32) | NONE;
     v3 o = mk3(0, 0, 0), d = mk3(0, 0, 0);
     float tmax = 0.0f;
     float ix = 0.0f, iy = 0.0f, iz = 0.0f, oix = 0.0f, oiy = 0.0f, oiz = 0.0f;
     unsigned long long best_key = NO_HIT_KEY;
-    uint32_t sp = 0, ref = IDLE;
+#if RVB_PAIR_PUSH_COUNTS
+    // the stack pointer is the LDS byte address of the pair's next free row (rows are PAIRS_PER_BLOCK words apart)
+    const uint32_t PAIR_ROW = PAIRS_PER_BLOCK * (uint32_t) sizeof(uint32_t);
+    const uint32_t bottom = (uint32_t) (uintptr_t) (lds_u32_ptr) stack;
+    typedef uint32_t walk_t __attribute__((ext_vector_type(2)));
+    walk_t walk = {IDLE, bottom};
+#define ref walk.x
+#define sp walk.y
+#define RVB_PAIR_POP() { if (sp != bottom) { sp -= PAIR_ROW; ref = *(lds_u32_ptr) (uintptr_t) sp; } else ref = NONE; }
+#define RVB_PAIR_EMPTY() sp = bottom
+#else
+    uint32_t sp = 0;
+#define RVB_PAIR_POP() { if (sp > 0) { --sp; ref = stack[sp * PAIRS_PER_BLOCK]; } else ref = NONE; }
+#define RVB_PAIR_EMPTY() sp = 0
+    uint32_t ref = IDLE;
+#endif
     uint32_t selx = 0, sely = 0, selz = 0;
+#if RVB_PAIR_PUSH_COUNTS
+    float limit = 0.0f;                  // culling distance of the best hit so far: changes in leaf steps, is read in node steps
+#define RVB_PAIR_LIMIT() limit = fmaf(__uint_as_float((uint32_t) (best_key >> 32)), cull_scale, sc.cull_abs)
+#else
+#define RVB_PAIR_LIMIT()
+#endif
 #define RVB_RESET_QUERY()                                                         \
     {                                                                             \
         ix = clamp_inv(d.x); iy = clamp_inv(d.y); iz = clamp_inv(d.z);            \
         oix = o.x * ix; oiy = o.y * iy; oiz = o.z * iz;                           \
         selx = slab_selector(ix); sely = slab_selector(iy); selz = slab_selector(iz); \
-        best_key = NO_HIT_KEY; sp = 0; ref = 0;                                   \
+        best_key = NO_HIT_KEY; RVB_PAIR_EMPTY(); ref = 0; RVB_PAIR_LIMIT();                                   \
     }
     if (job.next(o, d, tmax)) RVB_RESET_QUERY()
     for (;;) {
@@ -575,17 +622,52 @@ __device__ __forceinline__ void traverse_pairs_vote(const SceneDev & sc, uint32_
                 const uint4 * np = reinterpret_cast<const uint4 *>(node_base + (ref | child_off));
                 const uint4 n0 = np[0], n1 = np[1];
 #endif
+#if !RVB_PAIR_PUSH_COUNTS
                 const float limit = fmaf(__uint_as_float((uint32_t) (best_key >> 32)), cull_scale, sc.cull_abs);
+#endif
                 float tn0, tn1;
                 const bool ok0 = RVB_PAIR_SLAB(RVB_PAIR_SELECT & 1, n0, tn0, job.skip_ref());
                 const bool ok1 = RVB_PAIR_SLAB(RVB_PAIR_SELECT & 1, n1, tn1, job.skip_ref());
+#if RVB_PAIR_PUSH_COUNTS
+                // the hit children's keys: entry distance (its two low bits give way to the child number), compared as SIGNED integers —
+                // negative distances (the origin is inside the box, or the box a rounding behind it) come before all others, in any
+                // order; tools/travforms.cpp replays the same number of node visits as with keys of max(distance, 0)
+                const uint32_t NO_CHILD = 0x7FFFFFFFu;
+                // ((distance & ~3) | child) as one v_bitop3_b32 with register operands: issues at the rate of v_fma_f32, the and_or
+                // form at 0.6 of it (profiles/r04b_inst_probe.log)
+                const uint32_t key0 = ok0 ? __builtin_amdgcn_bitop3_b32(__float_as_uint(tn0), clear2, c0, 0xEA) : NO_CHILD;
+                const uint32_t key1 = ok1 ? __builtin_amdgcn_bitop3_b32(__float_as_uint(tn1), clear2, c1, 0xEA) : NO_CHILD;
+                uint32_t kmin = (uint32_t) min((int32_t) key0, (int32_t) key1);
+                kmin = (uint32_t) min((int32_t) kmin, (int32_t) dpp_u<QP_SWAP1>(kmin));
+                if (kmin == NO_CHILD) {
+#else
                 const uint32_t key0 = ok0 ? ((__float_as_uint(fmaxf(tn0, 0.0f)) & ~3u) | c0) : NONE;
                 const uint32_t key1 = ok1 ? ((__float_as_uint(fmaxf(tn1, 0.0f)) & ~3u) | c1) : NONE;
                 uint32_t kmin = min(key0, key1);
                 kmin = min(kmin, dpp_u<QP_SWAP1>(kmin));
                 if (kmin == NONE) {
-                    if (sp > 0) { --sp; ref = stack[sp * PAIRS_PER_BLOCK]; } else ref = NONE;
+#endif
+                    RVB_PAIR_POP()
                 } else {
+#if RVB_PAIR_PUSH_COUNTS
+                    // the pair's pushes in child order (as below) from the lanes' COUNTS: a lane's kept children go on top of the other
+                    // lane's if it is the pair's second lane, so one 2-bit count crosses the pair instead of the hit mask, and a lane's
+                    // rows follow from its own two flags (the keys name the child: key == kmin is the winner)
+                    const bool other0 = key0 != kmin, other1 = key1 != kmin;
+                    const bool keep0 = ok0 && other0, keep1 = ok1 && other1;
+                    const uint32_t first = keep0 ? PAIR_ROW : 0u;                          // counts in bytes of stack rows
+                    const uint32_t n_mine = first + (keep1 ? PAIR_ROW : 0u);
+                    const uint32_t n_theirs = dpp_u<QP_SWAP1>(n_mine);
+                    const uint32_t row = __umul24(n_theirs, h) + sp;                       // sp + (h ? n_theirs : 0) as one v_mad_u32_u24
+                    if (keep0)
+                        *(lds_u32_ptr) (uintptr_t) row = n0.w;
+                    if (keep1)
+                        *(lds_u32_ptr) (uintptr_t) (row + first) = n1.w;
+                    // the winner is the child whose key IS kmin (keys carry the child number)
+                    const uint32_t mine = other1 ? (other0 ? 0u : n0.w) : n1.w;            // 0 in the lane that does not own it
+                    sp += n_mine + n_theirs;
+                    ref = mine | dpp_u<QP_SWAP1>(mine);
+#else
                     const uint32_t winner = kmin & 3u;
                     uint32_t okmask = (ok0 ? bit0 : 0u) | (ok1 ? bit1 : 0u);
                     okmask |= dpp_u<QP_SWAP1>(okmask);
@@ -598,8 +680,10 @@ __device__ __forceinline__ void traverse_pairs_vote(const SceneDev & sc, uint32_
                     const uint32_t mine = (winner & 1u) ? n1.w : n0.w;
                     const uint32_t theirs = dpp_u<QP_SWAP1>(mine);
                     ref = (winner >> 1) == h ? mine : theirs;
+#endif
                 }
             }
+            continue;
         } else if (n_leaf >= n_done) {
             RVB_MARK("leaf");
             if ((int32_t) ref < (int32_t) IDLE) {
@@ -620,8 +704,10 @@ __device__ __forceinline__ void traverse_pairs_vote(const SceneDev & sc, uint32_
                 unsigned long long key = min_u64(k0, k1);
                 key = min_u64(key, dpp_u64<QP_SWAP1>(key));
                 best_key = min_u64(best_key, key);
-                if (sp > 0) { --sp; ref = stack[sp * PAIRS_PER_BLOCK]; } else ref = NONE;
+                RVB_PAIR_LIMIT();
+                RVB_PAIR_POP()
             }
+            continue;
         } else {
             RVB_MARK("done");
             if (ref == NONE) {
@@ -636,6 +722,13 @@ __device__ __forceinline__ void traverse_pairs_vote(const SceneDev & sc, uint32_
         RVB_MARK("loop_end");
     }
 #undef RVB_RESET_QUERY
+#undef RVB_PAIR_POP
+#undef RVB_PAIR_EMPTY
+#if RVB_PAIR_PUSH_COUNTS
+#undef ref
+#undef sp
+#endif
+#undef RVB_PAIR_LIMIT
 }
 
 // Any-hit query with two lanes per ray (shadow_pair_kernel): is there a triangle with EPSILON < distance <= tmax (the negation of
@@ -1000,7 +1093,8 @@ __global__ __launch_bounds__(WAVE, WAVES) void path_kernel(TraceArgs a)
 
 // path_kernel with two lanes per ray (traverse_pairs_vote): 32 rays per single-wave workgroup.
 #ifndef RVB_PAIR_WAVES
-#define RVB_PAIR_WAVES 4            // waves per SIMD the register budget allows (100 k rays are 3.05 waves per SIMD)
+#define RVB_PAIR_WAVES 6            // register cap: 80 VGPRs, so that six waves fit a SIMD beside the other kernels' (see RVB_PAIR_PUSH_COUNTS);
+                                    // 7 (72 VGPRs) spills ten registers: pipeline 4.52-4.54 ms against 4.37-4.40
 #endif
 template <bool SURF_LDS>
 __device__ __forceinline__ void path_pair_body(const TraceArgs & a, const uint32_t block)
@@ -1082,7 +1176,6 @@ __global__ __launch_bounds__(WAVE, RVB_PAIR_WAVES) void path_pair_group_kernel(T
 // in flight: rvb_path_lanes_for picks it for group launches of that size only.  Same arithmetic, same records, same bytes as the
 // other two path kernels (tests/test_gpu_parity.py runs every trace case with all three).
 #define LANE_RAYS 64
-typedef __attribute__((address_space(3))) uint32_t * lds_u32_ptr;
 typedef __attribute__((address_space(3))) void * lds_void_ptr;
 typedef const __attribute__((address_space(1))) void * global_void_ptr;
 #ifndef RVB_LANE_WAVES
@@ -1117,7 +1210,9 @@ __device__ __forceinline__ void path_lane_body(const TraceArgs & a, const uint32
     const lds_float4_ptr surf_lds = stage_surfaces(a, after_stack);
     uint16_t * const key_row = reinterpret_cast<uint16_t *>(after_stack + 16u * a.lds_surfaces) + lane * RVB_KEY_RUN;
     // (behind the key runs when there are any: rvb_lane_lds_bytes) the landing area of the cooperative node fetch
+#if RVB_LANE_COOP
     uint32_t * const stage = after_stack + 16u * a.lds_surfaces + (a.sort_keys16 ? LANE_RAYS * RVB_KEY_RUN / 2u : 0u);
+#endif
     const bool in_range = ray < a.nrays;
 #if !RVB_LANE_COOP
     if (!in_range)

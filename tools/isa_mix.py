@@ -42,16 +42,41 @@ def classify(op):
     return "unclassified: " + op
 
 
+# Issue cost of a vector instruction relative to v_fma_f32 with register operands, 8 waves per SIMD (tools/inst_probe.hip,
+# profiles/r04b_inst_probe.log): the binary32 add / mul / fma, the move, the two-operand integer add / sub, and / or / xor, the right
+# shift and v_bitop3_b32 issue at the fast rate, every other form (comparisons, selects, min / max, DPP, byte permute, fma_mix, the
+# three-operand integer forms, anything that reads an SGPR in a three-operand form) takes 1.6-1.8 times as long.
+FAST = re.compile(r"^v_(fma_f32|fmac_f32|add_f32|sub_f32|subrev_f32|mul_f32|mul_legacy_f32|mov_b32|bitop3_b32|and_b32|or_b32|xor_b32|lshrrev_b32|"
+                  r"add_u32|sub_u32|subrev_u32)(_e32|_e64)?$")
+
+
+def issue_cost(line):
+    op = line.split()[0]
+    if not op.startswith("v_"):
+        return 0.0
+    if re.match(r"^v_(rcp|rsq|sqrt)_f32", op):
+        return 3.1
+    if re.match(r"^v_rcp_f64", op):
+        return 6.2
+    if FAST.match(op) and "dpp" not in line and "sdwa" not in line:
+        operands = line.split(None, 1)[1] if len(line.split(None, 1)) > 1 else ""
+        if op.startswith("v_fma_f32") and re.search(r"(^|[ ,\-|])s(\d|\[)", operands):
+            return 1.75                  # a scalar operand in the three-operand form
+        return 1.0
+    return 1.7
+
+
 def main():
     steps = [float(x) for x in sys.argv[1:4]] if len(sys.argv) >= 4 else [28.66, 5.14, 2.57]      # travsim, C2, 32 rays per wave
     asm = "/tmp/isa_mix.s"
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
                            "-fhip-fp32-correctly-rounded-divide-sqrt", "-munsafe-fp-atomics", "-fno-slp-vectorize", "--cuda-device-only",
-                           "-DRVB_ISA_MARKS=1", "-S", "-o", asm, os.path.join(PKG, "csrc", "trace_kernels.hip")], cwd=PKG)
+                           "-DRVB_ISA_MARKS=1", *os.environ.get("ISA_MIX_FLAGS", "").split(), "-S", "-o", asm, os.path.join(PKG, "csrc", "trace_kernels.hip")], cwd=PKG)
     text = open(asm).read()
     start = text.index("_ZN12_GLOBAL__N_122path_pair_group_kernelILb1EEEvNS_10TraceGroupE:")
     body = text[start:text.index("s_endpgm", start)]
     blocks, current = collections.OrderedDict(), None
+    cost = collections.Counter()
     for line in body.splitlines():
         line = line.strip()
         m = re.match(r"; RVB_MARK (\w+)", line)
@@ -65,6 +90,7 @@ def main():
         if op in ("s_nop",) or op.startswith(";;#"):
             continue
         blocks[current][classify(op)] += 1
+        cost[current] += issue_cost(line)
     weights = {"vote": steps[0] + steps[1] + steps[2], "node": steps[0], "leaf": steps[1], "done": steps[2]}
     print("static instruction counts per block of traverse_pairs_vote (path_pair_kernel<true>), and per bounce of one wave (32 rays)")
     print("weights = wave-level executions per bounce: %s" % weights)
@@ -72,12 +98,12 @@ def main():
     for name, counter in blocks.items():
         n = sum(counter.values())
         valu = sum(v for k, v in counter.items() if not k.startswith(("LDS", "vector memory", "scalar")))
-        print("\n[%s] %d instructions, %d of them VALU, x %.2f per bounce" % (name, n, valu, weights.get(name, 0.0)))
+        print("\n[%s] %d instructions, %d of them VALU = %.1f issue units (v_fma_f32 = 1), x %.2f per bounce" % (name, n, valu, cost[name], weights.get(name, 0.0)))
         for k, v in counter.most_common():
             print("   %4d  %s" % (v, k))
             total[k] += v * weights.get(name, 0.0)
     valu_total = sum(v for k, v in total.items() if not k.startswith(("LDS", "vector memory", "scalar")))
-    print("\nper bounce of one wave, all blocks weighted: %.0f instructions, %.0f VALU" % (sum(total.values()), valu_total))
+    print("\nper bounce of one wave, all blocks weighted: %.0f instructions, %.0f VALU, %.0f issue units" % (sum(total.values()), valu_total, sum(cost[k] * weights.get(k, 0.0) for k in cost)))
     for k, v in total.most_common():
         share = "" if k.startswith(("LDS", "vector memory", "scalar")) else "  (%.1f %% of VALU)" % (100.0 * v / valu_total)
         print("   %7.0f  %s%s" % (v, k, share))
