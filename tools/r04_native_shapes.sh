@@ -2,7 +2,7 @@
 # round 4: shapes of the native pipeline (contexts / traces per group launch)
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-out=gpurun_out/r04_native_pipeline_shapes_n1.txt
+out=gpurun_out/${SHAPES_TAG:-r04_native_pipeline_shapes_n1}.txt
 : > $out
 for cfg in "4 2" "8 4" "6 3" "8 2" "6 2" "4 1" "2 1" "4 4" "8 4"; do
     set -- $cfg
