@@ -1094,7 +1094,8 @@ __global__ __launch_bounds__(WAVE, WAVES) void path_kernel(TraceArgs a)
 // path_kernel with two lanes per ray (traverse_pairs_vote): 32 rays per single-wave workgroup.
 #ifndef RVB_PAIR_WAVES
 #define RVB_PAIR_WAVES 6            // register cap: 80 VGPRs, so that six waves fit a SIMD beside the other kernels' (see RVB_PAIR_PUSH_COUNTS);
-                                    // 7 (72 VGPRs) spills ten registers: pipeline 4.52-4.54 ms against 4.37-4.40
+                                    // 7 (72 VGPRs) spills ten registers: pipeline 4.52-4.54 ms against 4.37-4.40, and 4.70 against 4.47 when LDS
+                                    // allows the seventh wave too (no key runs: profiles/r04c_occupancy_n1.txt); 8 (64 VGPRs): 5.9 ms
 #endif
 template <bool SURF_LDS>
 __device__ __forceinline__ void path_pair_body(const TraceArgs & a, const uint32_t block)
