@@ -41,7 +41,7 @@ from parallel_reverb_raytracer_amd import capi, distributed, dtypes, scenes  # n
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 # the guide's vector issue rate: v_fma_f32 (wave64) 2 cycles on each of 256 x 4 SIMDs at 2.4 GHz
 VALU_FMA_PEAK_GINST = 256 * 4 * 2.4 / 2
-PMC_FILE = "r04_pmc_n1.json"      # committed PMC passes of this command (tools/profile.sh): instruction mix, lane utilisation, HBM bytes
+PMC_FILE = "r04c_pmc_n1.json"      # committed PMC passes of this command (tools/profile.sh): instruction mix, lane utilisation, HBM bytes
 BYTES_PER_BOUNCE = 69.75          # 64 B Impulse per bounce + (16 B direction + 10 x 72 B image slots) per ray at 128 bounces
 
 
