@@ -63,6 +63,7 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     p.add_argument("--rehearse-collectives", action="store_true",
                    help="with one rank: create the process group anyway and run every collective of the multi-GPU path on it")
+    p.add_argument("--own-scenes", action="store_true", help="every context builds and uploads a copy of the scene of its own (before round 4's rvb_share_scene)")
     p.add_argument("--exact-chain", action="store_true", help="several ranks, exact mode: the ranks continue ONE serial sum in ray order (bit-identical "
                    "to one GPU; their binning stages run one after the other) instead of all-reducing their own serial sums")
     p.add_argument("--no-host-copy", action="store_true", help="leave the finished histograms in HBM (the round-1/2 metric; diagnostic)")
@@ -217,9 +218,12 @@ def main():
     contexts, scene_ms = [], 0.0
     for _ in range(max(1, args.contexts)):
         c = capi.Context(local_rank)
-        t0 = time.perf_counter()
-        c.set_scene(scene)
-        scene_ms = (time.perf_counter() - t0) * 1e3
+        if contexts and not args.own_scenes:
+            c.share_scene(contexts[0])          # one hierarchy in HBM (and in the L2s) for all the contexts of this GPU: rvb_share_scene
+        else:
+            t0 = time.perf_counter()
+            c.set_scene(scene)
+            scene_ms = (time.perf_counter() - t0) * 1e3
         c.set_directions_device(dirs.data_ptr(), nrays)
         contexts.append(c)
     ctx = contexts[0]

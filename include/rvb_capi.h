@@ -82,6 +82,12 @@ int rvb_set_scene(rvb_ctx * ctx,
                   const rvb_triangle * triangles, uint64_t ntriangles,
                   const rvb_float3 * vertices, uint64_t nvertices,
                   const rvb_surface * surfaces, uint64_t nsurfaces);
+/* Gives `ctx` the scene `from` holds — the SAME device buffers, no second build, no second copy: the contexts of one GPU that trace
+ * side by side in one room (rvb_pipeline_*, rvb_trace_group; the reference builds one Raytracer per scene, rayverb.cpp:242-293) then
+ * keep one hierarchy in HBM and in the L2s instead of one each.  The buffers live as long as any context holds them; a later
+ * rvb_set_scene on either context gives THAT context a scene of its own and leaves the other's untouched.
+ * RVB_ERR_STATE: `from` has no scene; RVB_ERR_INVALID: the contexts are on different devices. */
+int rvb_share_scene(rvb_ctx * ctx, rvb_ctx * from);
 /* BVH statistics of the current scene (nodes, leaf triangles kept, tree depth). */
 int rvb_scene_info(rvb_ctx * ctx, uint64_t * nodes, uint64_t * kept_triangles, uint32_t * depth);
 

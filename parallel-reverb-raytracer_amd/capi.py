@@ -24,7 +24,7 @@ IR_FAST, IR_EXACT = 0, 1
 # every symbol include/rvb_capi.h declares
 SYMBOLS = [
     "rvb_create", "rvb_destroy", "rvb_last_error", "rvb_synchronize", "rvb_wait_for_event", "rvb_device_info",
-    "rvb_set_scene", "rvb_scene_info", "rvb_set_directions", "rvb_set_directions_device", "rvb_set_concurrent_traces", "rvb_set_path_lanes", "rvb_trace", "rvb_trace_group",
+    "rvb_set_scene", "rvb_share_scene", "rvb_scene_info", "rvb_set_directions", "rvb_set_directions_device", "rvb_set_concurrent_traces", "rvb_set_path_lanes", "rvb_trace", "rvb_trace_group",
     "rvb_trace_pairs", "rvb_ir_select_pair",
     "rvb_get_diffuse", "rvb_diffuse_device", "rvb_get_direct", "rvb_get_image_candidates", "rvb_merge_images",
     "rvb_attenuate_speaker", "rvb_attenuate_speaker_device", "rvb_attenuate_hrtf", "rvb_attenuate_hrtf_device", "rvb_flatten",
@@ -158,6 +158,10 @@ class Context:
         triangles, vertices, surfaces = (np.ascontiguousarray(x) for x in (triangles, vertices, surfaces))
         self._check(self.lib.rvb_set_scene(self.handle, _ptr(triangles), _u64(triangles.shape[0]), _ptr(vertices),
                                            _u64(vertices.shape[0]), _ptr(surfaces), _u64(surfaces.shape[0])))
+
+    def share_scene(self, other):
+        """This context reads the scene `other` holds: the same device buffers, no second build or copy (rvb_share_scene)."""
+        self._check(self.lib.rvb_share_scene(self.handle, other.handle))
 
     def scene_info(self):
         nodes, kept, depth = _u64(0), _u64(0), ctypes.c_uint32(0)

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -38,6 +39,22 @@ struct Timing { std::string name; hipEvent_t start, stop; };
 
 }  // namespace
 
+// The scene's device buffers: built and uploaded once (rvb_set_scene), read by every context that holds the store (rvb_share_scene) —
+// one copy in HBM, and ONE copy for the L2s to keep, however many contexts trace in it side by side.  Freed with its last holder.
+struct SceneStore {
+    int device = 0;
+    DevBuf nodes, tris, shade, corners, surfaces;
+    SceneStore() = default;
+    SceneStore(const SceneStore &) = delete;
+    SceneStore & operator=(const SceneStore &) = delete;
+    ~SceneStore()
+    {
+        (void) hipSetDevice(device);
+        for (DevBuf * b : {&nodes, &tris, &shade, &corners, &surfaces})
+            b->release();
+    }
+};
+
 struct rvb_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -53,7 +70,7 @@ struct rvb_ctx {
 
     // scene
     bool have_scene = false;
-    DevBuf nodes, tris, shade, corners, surfaces;
+    std::shared_ptr<SceneStore> store;          // (its own after rvb_set_scene, another context's after rvb_share_scene)
     SceneDev scene;
     uint64_t nnodes = 0, kept = 0;
     uint32_t depth = 0;
@@ -254,7 +271,8 @@ void rvb_destroy(rvb_ctx * ctx)
         return;
     (void) hipSetDevice(ctx->device);
     if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
-    for (DevBuf * b : {&ctx->nodes, &ctx->tris, &ctx->shade, &ctx->corners, &ctx->surfaces, &ctx->sort_keys, &ctx->sort_scratch, &ctx->sort_order, &ctx->group_temp, &ctx->directions_own, &ctx->impulses, &ctx->image_items,
+    ctx->store.reset();
+    for (DevBuf * b : {&ctx->sort_keys, &ctx->sort_scratch, &ctx->sort_order, &ctx->group_temp, &ctx->directions_own, &ctx->impulses, &ctx->image_items,
                        &ctx->early, &ctx->candidates, &ctx->small, &ctx->stamps, &ctx->images, &ctx->hrtf_table, &ctx->acc, &ctx->keys_a,
                        &ctx->keys_b, &ctx->vals_a, &ctx->vals_b, &ctx->sort_temp, &ctx->scratch_in, &ctx->scratch_out, &ctx->flat_in, &ctx->hist, &ctx->bin_starts, &ctx->own_sort_temp, &ctx->own_sort_keys, &ctx->own_sort_values,
                        &ctx->pair_geom, &ctx->pair_direct, &ctx->pair_range})
@@ -341,24 +359,30 @@ int rvb_set_scene(rvb_ctx * ctx, const rvb_triangle * triangles, uint64_t ntrian
     RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->have_scene = false;
     ctx->traced = false;
+    // a store other contexts hold stays theirs: this context gets a new one (buffers it holds alone are reused)
+    if (!ctx->store || ctx->store.use_count() > 1) {
+        ctx->store = std::make_shared<SceneStore>();
+        ctx->store->device = ctx->device;
+    }
+    SceneStore & st = *ctx->store;
     auto upload = [&](DevBuf & b, const void * src, size_t bytes) -> hipError_t {
         hipError_t e = b.ensure(bytes);
         if (e != hipSuccess || bytes == 0) return e;
         return hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice);
     };
-    RVB_HIP(ctx, upload(ctx->nodes, built.nodes.data(), built.nodes.size() * sizeof(BvhNode)));
-    RVB_HIP(ctx, upload(ctx->tris, built.tris.data(), built.tris.size() * sizeof(BvhTri)));
+    RVB_HIP(ctx, upload(st.nodes, built.nodes.data(), built.nodes.size() * sizeof(BvhNode)));
+    RVB_HIP(ctx, upload(st.tris, built.tris.data(), built.tris.size() * sizeof(BvhTri)));
     // the eighth word of a shading record (the builder's plane-group number, of no use on the device) carries the triangle's position
     // in leaf order: the path kernel's record-grouping key comes with the 32 bytes it reads anyway instead of from a gather of its own
     for (size_t i = 0; i < built.shade.size() && i < built.leafpos.size(); ++i) built.shade[i].group = built.leafpos[i];
-    RVB_HIP(ctx, upload(ctx->shade, built.shade.data(), built.shade.size() * sizeof(TriShade)));
-    RVB_HIP(ctx, upload(ctx->corners, built.corners.data(), built.corners.size() * sizeof(TriCorners)));
-    RVB_HIP(ctx, upload(ctx->surfaces, surfaces, nsurfaces * sizeof(rvb_surface)));
-    ctx->scene.nodes = ctx->nodes.as<const BvhNode>();
-    ctx->scene.tris = ctx->tris.as<const BvhTri>();
-    ctx->scene.shade = ctx->shade.as<const TriShade>();
-    ctx->scene.corners = ctx->corners.as<const TriCorners>();
-    ctx->scene.surfaces = ctx->surfaces.as<const rvb_surface>();
+    RVB_HIP(ctx, upload(st.shade, built.shade.data(), built.shade.size() * sizeof(TriShade)));
+    RVB_HIP(ctx, upload(st.corners, built.corners.data(), built.corners.size() * sizeof(TriCorners)));
+    RVB_HIP(ctx, upload(st.surfaces, surfaces, nsurfaces * sizeof(rvb_surface)));
+    ctx->scene.nodes = st.nodes.as<const BvhNode>();
+    ctx->scene.tris = st.tris.as<const BvhTri>();
+    ctx->scene.shade = st.shade.as<const TriShade>();
+    ctx->scene.corners = st.corners.as<const TriCorners>();
+    ctx->scene.surfaces = st.surfaces.as<const rvb_surface>();
     ctx->scene.ntris = (uint32_t) built.tris.size();
     // cull slack along the ray: the float distance of a triangle may differ from the exact one
     ctx->scene.cull_abs = built.pad;
@@ -369,6 +393,26 @@ int rvb_set_scene(rvb_ctx * ctx, const rvb_triangle * triangles, uint64_t ntrian
     ctx->stack_need = built.stack_need;
     ctx->nsurfaces = nsurfaces;
     ctx->have_scene = true;
+    return RVB_OK;
+}
+
+int rvb_share_scene(rvb_ctx * ctx, rvb_ctx * from)
+{
+    if (!ctx || !from) return RVB_ERR_INVALID;
+    if (ctx == from) return RVB_OK;
+    if (!from->have_scene || !from->store) return fail(ctx, RVB_ERR_STATE, "rvb_share_scene: the other context holds no scene");
+    if (from->device != ctx->device) return fail(ctx, RVB_ERR_INVALID, "rvb_share_scene: the contexts are on different devices (a scene is shared within one GPU's memory)");
+    RVB_BIND(ctx);
+    RVB_HIP(ctx, hipStreamSynchronize(ctx->stream));        // nothing of this context reads its old scene any more
+    ctx->store = from->store;
+    ctx->scene = from->scene;
+    ctx->nnodes = from->nnodes;
+    ctx->kept = from->kept;
+    ctx->depth = from->depth;
+    ctx->stack_need = from->stack_need;
+    ctx->nsurfaces = from->nsurfaces;
+    ctx->have_scene = true;
+    ctx->traced = false;
     return RVB_OK;
 }
 

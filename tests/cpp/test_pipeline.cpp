@@ -134,7 +134,9 @@ int main(int argc, char ** argv)
     for (int i = 0; i <= NCTX; ++i) {
         const int rc = rvb_create(&ctxs[i], 0, 0);
         if (rc != RVB_OK) { std::printf("rvb_create: %s\n", rvb_last_error(nullptr)); return 2; }      // no GPU: there is no CPU path
-        OK(rvb_set_scene(ctxs[i], scene.tris.data(), scene.tris.size(), scene.verts.data(), scene.verts.size(), scene.surfaces.data(), scene.surfaces.size()));
+        // the pipeline's contexts 1-3 read context 0's scene (rvb_share_scene); the solo context builds its own
+        if (i == 0 || i == NCTX) OK(rvb_set_scene(ctxs[i], scene.tris.data(), scene.tris.size(), scene.verts.data(), scene.verts.size(), scene.surfaces.data(), scene.surfaces.size()));
+        else OK(rvb_share_scene(ctxs[i], ctxs[0]));
         OK(rvb_set_directions(ctxs[i], dirs.data(), dirs.size()));
     }
     rvb_ctx * solo = ctxs[NCTX];

@@ -18,8 +18,11 @@ def rig():
     scene, info = scenes.concert_hall(6000)
     dirs = scenes.sphere_directions(9000, seed=31)
     ctxs = [capi.Context(0) for _ in range(5)]
-    for c in ctxs:
-        c.set_scene(scene)
+    for k, c in enumerate(ctxs):
+        if k in (1, 2, 3):
+            c.share_scene(ctxs[0])          # the pipeline's contexts read ONE copy of the scene (rvb_share_scene); the solo context has its own
+        else:
+            c.set_scene(scene)
         c.set_directions(dirs)
     src, mic = scenes.source_mic_pairs(9, seed=5)
     yield ctxs[:4], ctxs[4], [(tuple(float(x) for x in m), tuple(float(x) for x in s)) for s, m in zip(src, mic)]      # (microphone, source)
@@ -125,3 +128,38 @@ def test_hrtf_table_stays_on_the_device_for_table_none(rig):
             ctx.ir_configure_hrtf(mic, None, (0.0, 0.0, 1.0), (0.0, 1.0, 0.0))
     finally:
         ctx.close()
+
+
+def test_a_shared_scene_outlives_its_first_holder_and_a_new_scene_on_one_context_leaves_the_other_alone():
+    """rvb_share_scene: the sharer traces the same bytes as the holder; the holder may then load another scene or be destroyed —
+    the sharer keeps the buffers it was given; a context without a scene cannot be shared from."""
+    from parallel_reverb_raytracer_amd import capi
+    hall, _ = scenes.concert_hall(5000)
+    room = scenes.shoebox()
+    dirs = scenes.sphere_directions(4000, seed=3)
+    src, mic = scenes.source_mic_pairs(1, seed=9)
+    mic, src = tuple(float(x) for x in mic[0]), tuple(float(x) for x in src[0])
+    holder, sharer, empty = capi.Context(0), capi.Context(0), capi.Context(0)
+    try:
+        with pytest.raises(capi.RvbError):
+            sharer.share_scene(empty)
+        holder.set_scene(hall)
+        sharer.share_scene(holder)
+        assert sharer.scene_info() == holder.scene_info()
+        for c in (holder, sharer):
+            c.set_directions(dirs)
+        want, _ = _solo(holder, mic, src, capi.IR_EXACT, capi.IR_ALL, True)
+        got, _ = _solo(sharer, mic, src, capi.IR_EXACT, capi.IR_ALL, True)
+        assert np.array_equal(got, want) and want.any()
+        holder.set_scene(room)                        # the holder moves on: a scene of its own, the shared buffers stay the sharer's
+        assert holder.scene_info() != sharer.scene_info()
+        again, _ = _solo(sharer, mic, src, capi.IR_EXACT, capi.IR_ALL, True)
+        assert np.array_equal(again, want)
+        holder.close()
+        holder = None
+        last, _ = _solo(sharer, mic, src, capi.IR_EXACT, capi.IR_ALL, True)
+        assert np.array_equal(last, want)
+    finally:
+        for c in (holder, sharer, empty):
+            if c is not None:
+                c.close()

@@ -72,7 +72,10 @@ def pairs_pipelined(scene, src, mic, nrays, nrefl, npairs):
     ctxs = []
     for _ in range(2):
         c = capi.Context(0)
-        c.set_scene(scene)
+        if ctxs:
+            c.share_scene(ctxs[0])              # one copy of the scene for the contexts of the GPU
+        else:
+            c.set_scene(scene)
         c.set_directions_device(dirs.data_ptr(), nrays)
         ctxs.append(c)
     device = torch.device("cuda", 0)
@@ -129,7 +132,10 @@ def native_pipeline(name, scene, jobs, nrays, nrefl, hrtf, contexts=4, repeats=3
     ctxs = []
     for _ in range(contexts):
         c = capi.Context(0)
-        c.set_scene(scene)
+        if ctxs:
+            c.share_scene(ctxs[0])              # one copy of the scene for the contexts of the GPU
+        else:
+            c.set_scene(scene)
         c.set_directions_device(dirs.data_ptr(), nrays)
         ctxs.append(c)
     pipe = capi.Pipeline(ctxs)
