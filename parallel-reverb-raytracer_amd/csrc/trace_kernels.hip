@@ -744,7 +744,7 @@ __device__ __forceinline__ bool traverse_pair_any(const SceneDev & sc, const v3 
     const uint32_t bit0 = 1u << c0, bit1 = 2u << c0, lt0 = bit0 - 1u, lt1 = bit1 - 1u;
     const char * node_base = reinterpret_cast<const char *>(sc.nodes);
     const char * tri_base = reinterpret_cast<const char *>(sc.tris);
-    const uint32_t child_off = 32u * h;
+    const uint32_t child_off = 32u * h;                                    // (pinned in a register it would be the 81st: a wave per SIMD less)
     const float neg_cull = -sc.cull_abs;
     const float limit = fmaf(tmax, 1.0f + sc.cull_rel, sc.cull_abs);
     const float ix = clamp_inv(d.x), iy = clamp_inv(d.y), iz = clamp_inv(d.z);
