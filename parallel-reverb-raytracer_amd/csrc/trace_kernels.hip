@@ -541,6 +541,9 @@ __device__ __forceinline__ void traverse_jobs_vote(const SceneDev & sc, uint32_t
 #ifndef RVB_PAIR_PUSH_COUNTS
 #define RVB_PAIR_PUSH_COUNTS 1
 #endif
+#ifndef RVB_PAIR_SHORT_VOTE
+#define RVB_PAIR_SHORT_VOTE 1
+#endif
 #define RVB_PAIR_SLAB(SEL, n, tn, skip) ((SEL) ? slab_select(n, ix, iy, iz, oix, oiy, oiz, selx, sely, selz, limit, neg_cull, skip, tn) \
                                                : slab(n, ix, iy, iz, oix, oiy, oiz, limit, neg_cull, skip, tn))
 template <class Job>
@@ -596,17 +599,63 @@ __device__ __forceinline__ void traverse_pairs_vote(const SceneDev & sc, uint32_
         selx = slab_selector(ix); sely = slab_selector(iy); selz = slab_selector(iz); \
         best_key = NO_HIT_KEY; RVB_PAIR_EMPTY(); ref = 0; RVB_PAIR_LIMIT();                                   \
     }
+#if RVB_STAMPS
+    // diagnostic builds.  -DRVB_STAMPS=1: where a wave's cycles go — [0] vote, [1] node step until its two loads are back, [2] the rest of the
+    // node step (incl. the wait for the popped entry), [3] / [4] the same for leaf steps, [5] shading steps; [6..8] step counts.  Any RVB_STAMPS
+    // (2 = these alone, the loop runs at its own pace): [9] shader cycles and [11] 100-MHz ticks of the whole loop — their quotient is the
+    // clock the chip holds under this load (MI355X_MICROARCH.md "DVFS give-back") —, [10] waves
+    unsigned long long sv[6] = {0, 0, 0, 0, 0, 0}, sn[3] = {0, 0, 0}, t_loop, r_loop, t_a = 0, t_b = 0, t_c = 0;
+    STAMP(t_loop)
+    { __builtin_amdgcn_sched_barrier(0); r_loop = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); }
+    t_c = t_loop;
+#endif
     if (job.next(o, d, tmax)) RVB_RESET_QUERY()
+#if RVB_PAIR_SHORT_VOTE
+    // lanes that carry a ray (not IDLE): changes in shading steps only
+    int n_active = scalar_popcount(__builtin_amdgcn_ballot_w64(ref != IDLE));
+#endif
     for (;;) {
         RVB_MARK("vote");
+#if RVB_PAIR_SHORT_VOTE
+        // The vote, short form: a wave's time goes into the LATENCY of its instructions (a dependent scalar chain behind three ballots is
+        // 300 of an iteration's 1 900 cycles, tools/pair_stamps.py), and four iterations in five are node steps.  When the lanes at a node
+        // are half of the live lanes or more they are the largest group whatever the other two counts are: those are then not formed.
+        // Alone on the GPU 3.54 -> 3.46 ms (100 k rays), 1.98 -> 1.94 ms per 100 k rays at 800 k; pipeline 4.30 -> 4.24 ms per IR
+        // (profiles/r04c_short_vote_n1.txt).  What does NOT help a wave's latency: requesting one dword of the next node before the
+        // vote so that the step's loads find the line in the L1 — 3.40 -> 3.81 ms alone, 4.23 -> 4.49 in the pipeline, and worse
+        // with the leaf's first triangle too (profiles/r04c_prefetch_n1.txt): a third access per step costs the L1 more than the
+        // 300 cycles of head start are worth, as with the one-lane kernel's four.
+        if (n_active == 0)
+            break;
+        const int n_node = scalar_popcount(__builtin_amdgcn_ballot_w64((int32_t) ref >= 0));
+        int n_done = 0, n_leaf = 0;
+        if (2 * n_node < n_active) {
+            n_done = scalar_popcount(__builtin_amdgcn_ballot_w64(ref == NONE));
+            n_leaf = scalar_popcount(__builtin_amdgcn_ballot_w64((int32_t) ref < (int32_t) IDLE));
+        }
+#else
         const unsigned long long m_node = __builtin_amdgcn_ballot_w64((int32_t) ref >= 0);
         const unsigned long long m_done = __builtin_amdgcn_ballot_w64(ref == NONE);
         const unsigned long long m_leaf = __builtin_amdgcn_ballot_w64((int32_t) ref < (int32_t) IDLE);
         const int n_node = scalar_popcount(m_node), n_done = scalar_popcount(m_done), n_leaf = scalar_popcount(m_leaf);
         if ((n_node | n_done | n_leaf) == 0)
             break;
+#endif
+#if RVB_STAMPS == 1
+        STAMP(t_a)
+        sv[0] += t_a - t_c;
+#endif
         if (n_node >= n_leaf && n_node >= n_done) {
             RVB_MARK("node");
+#if RVB_STAMPS == 1
+            if ((int32_t) ref >= 0) {
+                const uint4 * pp = reinterpret_cast<const uint4 *>(node_base + (ref | child_off));
+                uint4 w0 = pp[0], w1 = pp[1];
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0.x), "+v"(w1.x) :: "memory");     // the step's own loads hit the L1 afterwards
+            }
+            STAMP(t_b)
+            sv[1] += t_b - t_a; sn[0] += 1;
+#endif
             if ((int32_t) ref >= 0) {
 #if RVB_LDS_NODES
                 uint4 n0, n1;
@@ -683,9 +732,24 @@ __device__ __forceinline__ void traverse_pairs_vote(const SceneDev & sc, uint32_
 #endif
                 }
             }
+#if RVB_STAMPS == 1
+            STAMP(t_c)
+            sv[2] += t_c - t_b;
+#endif
             continue;
         } else if (n_leaf >= n_done) {
             RVB_MARK("leaf");
+#if RVB_STAMPS == 1
+            if ((int32_t) ref < (int32_t) IDLE) {
+                const uint32_t first = ref & 0x0FFFFFFFu, count = ((ref >> 28) & 7u) + 1u;
+                const float4 * q0 = reinterpret_cast<const float4 *>(tri_base + tri_byte_offset(first + (h < count ? h : 0u)));
+                const float4 * q1 = reinterpret_cast<const float4 *>(tri_base + tri_byte_offset(first + (h + 2u < count ? h + 2u : 0u)));
+                float4 w0 = q0[0], w1 = q0[2], w2 = q1[0], w3 = q1[2];
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0.x), "+v"(w1.x), "+v"(w2.x), "+v"(w3.x) :: "memory");
+            }
+            STAMP(t_b)
+            sv[3] += t_b - t_a; sn[1] += 1;
+#endif
             if ((int32_t) ref < (int32_t) IDLE) {
                 // triangles h and h + 2 of the leaf (a two-triangle leaf gives each lane one)
                 const uint32_t first = ref & 0x0FFFFFFFu;
@@ -707,6 +771,10 @@ __device__ __forceinline__ void traverse_pairs_vote(const SceneDev & sc, uint32_
                 RVB_PAIR_LIMIT();
                 RVB_PAIR_POP()
             }
+#if RVB_STAMPS == 1
+            STAMP(t_c)
+            sv[4] += t_c - t_b;
+#endif
             continue;
         } else {
             RVB_MARK("done");
@@ -718,9 +786,30 @@ __device__ __forceinline__ void traverse_pairs_vote(const SceneDev & sc, uint32_
                 ref = IDLE;
                 if (job.next(o, d, tmax)) RVB_RESET_QUERY()
             }
+#if RVB_PAIR_SHORT_VOTE
+            n_active = scalar_popcount(__builtin_amdgcn_ballot_w64(ref != IDLE));
+#endif
         }
+#if RVB_STAMPS == 1
+        STAMP(t_c)
+        sv[5] += t_c - t_a; sn[2] += 1;
+#endif
         RVB_MARK("loop_end");
     }
+#if RVB_STAMPS
+    if (sc.stamps) {
+        STAMP(t_b)
+        unsigned long long r_end;
+        { __builtin_amdgcn_sched_barrier(0); r_end = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); }
+        if ((threadIdx.x & 63u) == 0) {
+            for (int i = 0; i < 6; ++i) atomicAdd(sc.stamps + i, sv[i]);
+            for (int i = 0; i < 3; ++i) atomicAdd(sc.stamps + 6 + i, sn[i]);
+            atomicAdd(sc.stamps + 9, t_b - t_loop);
+            atomicAdd(sc.stamps + 10, 1ull);
+            atomicAdd(sc.stamps + 11, r_end - r_loop);
+        }
+    }
+#endif
 #undef RVB_RESET_QUERY
 #undef RVB_PAIR_POP
 #undef RVB_PAIR_EMPTY
