@@ -41,6 +41,9 @@
 #ifndef RVB_SHADOW_JOBS
 #define RVB_SHADOW_JOBS 0
 #endif
+#ifndef RVB_PAIR_SHORT_VOTE
+#define RVB_PAIR_SHORT_VOTE 1      // the vote loops' short form (traverse_pairs_vote, traverse_jobs_vote): one ballot when the lanes at a node are a majority
+#endif
 #ifndef RVB_LDS_NODES
 #define RVB_LDS_NODES 0        // experiment: top nodes of the BVH staged in LDS per workgroup (path_kernel); 21 = levels 0-2
 #endif
@@ -437,13 +440,28 @@ __device__ __forceinline__ void traverse_jobs_vote(const SceneDev & sc, uint32_t
         best_key = NO_HIT_KEY; sp = 0; ref = 0;                                   \
     }
     if (job.next(o, d, tmax)) RVB_RESET_QUERY()
+#if RVB_PAIR_SHORT_VOTE
+    int n_active = scalar_popcount(__builtin_amdgcn_ballot_w64(ref != IDLE));      // lanes that carry a ray: changes in shading steps only
+#endif
     for (;;) {
+#if RVB_PAIR_SHORT_VOTE
+        // the short form of the vote (traverse_pairs_vote): lanes at a node that are half of the live lanes or more ARE the largest group
+        if (n_active == 0)
+            break;
+        const int n_node = scalar_popcount(__builtin_amdgcn_ballot_w64((int32_t) ref >= 0));
+        int n_done = 0, n_leaf = 0;
+        if (2 * n_node < n_active) {
+            n_done = scalar_popcount(__builtin_amdgcn_ballot_w64(ref == NONE));
+            n_leaf = scalar_popcount(__builtin_amdgcn_ballot_w64((int32_t) ref < (int32_t) IDLE));   // signed: leaves are < -2
+        }
+#else
         const unsigned long long m_node = __builtin_amdgcn_ballot_w64((int32_t) ref >= 0);
         const unsigned long long m_done = __builtin_amdgcn_ballot_w64(ref == NONE);
         const unsigned long long m_leaf = __builtin_amdgcn_ballot_w64((int32_t) ref < (int32_t) IDLE);   // signed: leaves are < -2
         const int n_node = scalar_popcount(m_node), n_done = scalar_popcount(m_done), n_leaf = scalar_popcount(m_leaf);
         if ((n_node | n_done | n_leaf) == 0)
             break;
+#endif
         if (n_node >= n_leaf && n_node >= n_done) {
             if ((int32_t) ref >= 0) {
 #if RVB_LDS_NODES
@@ -507,6 +525,9 @@ __device__ __forceinline__ void traverse_jobs_vote(const SceneDev & sc, uint32_t
                 ref = IDLE;
                 if (job.next(o, d, tmax)) RVB_RESET_QUERY()
             }
+#if RVB_PAIR_SHORT_VOTE
+            n_active = scalar_popcount(__builtin_amdgcn_ballot_w64(ref != IDLE));
+#endif
         }
     }
 #undef RVB_RESET_QUERY
@@ -540,9 +561,6 @@ __device__ __forceinline__ void traverse_jobs_vote(const SceneDev & sc, uint32_t
 // bound by the latency of its chains) the kernel takes 3.49 ms either way.
 #ifndef RVB_PAIR_PUSH_COUNTS
 #define RVB_PAIR_PUSH_COUNTS 1
-#endif
-#ifndef RVB_PAIR_SHORT_VOTE
-#define RVB_PAIR_SHORT_VOTE 1
 #endif
 #define RVB_PAIR_SLAB(SEL, n, tn, skip) ((SEL) ? slab_select(n, ix, iy, iz, oix, oiy, oiz, selx, sely, selz, limit, neg_cull, skip, tn) \
                                                : slab(n, ix, iy, iz, oix, oiy, oiz, limit, neg_cull, skip, tn))
