@@ -445,7 +445,10 @@ __device__ __forceinline__ void traverse_jobs_vote(const SceneDev & sc, uint32_t
 #endif
     for (;;) {
 #if RVB_PAIR_SHORT_VOTE
-        // the short form of the vote (traverse_pairs_vote): lanes at a node that are half of the live lanes or more ARE the largest group
+        // the short form of the vote (traverse_pairs_vote): lanes at a node that are half of the live lanes or more ARE the largest group.
+        // Alone at 100 k rays 3.54 -> 3.31 ms (profiles/r04c_short_vote_quads_n1.txt).  The pair loop's other changes — signed keys built
+        // with v_bitop3, the culling distance as state, the winner's reference by two DPP ORs instead of ds_bpermute — change nothing
+        // here (3.29-3.36 ms with and without, profiles/r04c_quad_lean_n1.txt) and were not kept.
         if (n_active == 0)
             break;
         const int n_node = scalar_popcount(__builtin_amdgcn_ballot_w64((int32_t) ref >= 0));
