@@ -203,6 +203,8 @@ struct RayState { v3 o, d; uint32_t bounce, skip, tri; bool alive; uint32_t id; 
 struct Result { double ray_node, ray_leaf, wave_node, wave_leaf, wave_done, act_node, act_leaf, act_done, cost; unsigned long long bounces; unsigned long long checksum; };
 
 // one wave runs its rays for up to `bounces_here` bounces each (vote loop of traverse_pairs_vote)
+static unsigned long long g_votes = 0;
+static const bool g_chain = getenv("TRAVFORMS_CHAIN") != nullptr;
 static void run_wave(Sim & s, std::vector<RayState *> & rays, uint32_t stop_bounce, uint32_t nrefl, unsigned long long cnt[3], unsigned long long act[3],
                      unsigned long long & bounces, unsigned long long & checksum)
 {
@@ -220,6 +222,17 @@ static void run_wave(Sim & s, std::vector<RayState *> & rays, uint32_t stop_boun
         int a = NODE;                                            // n_node >= n_leaf && n_node >= n_done, else leaf >= done, else done
         if (!(c[0] >= c[1] && c[0] >= c[2])) a = c[1] >= c[2] ? LEAF : DONE;
         ++cnt[a]; act[a] += c[a];
+        ++g_votes;
+        for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) {
+            // TRAVFORMS_CHAIN=1: a leaf or shading step is followed by a node step for the lanes that are at a node by then, without a vote
+            if (!g_chain || a == NODE) break;
+            a = NODE;
+            int at_node = 0;
+            for (int i = 0; i < nq; ++i) at_node += st[i] == NODE;
+            if (!at_node) break;
+            ++cnt[a]; act[a] += at_node;
+        }
         for (int i = 0; i < nq; ++i) {
             if (st[i] != (St) a) continue;
             if (a == NODE) { s.node_step(q[i]); classify(i); }
@@ -250,6 +263,7 @@ static void run_wave(Sim & s, std::vector<RayState *> & rays, uint32_t stop_boun
                 s.begin(q[i], r.o, r.d, r.skip);
                 st[i] = NODE;
             }
+        }
         }
     }
 }
@@ -339,6 +353,7 @@ int main(int argc, char ** argv)
     for (size_t i = 0; i < forms.size(); ++i) {
         const Form & f = forms[i];
         if (only && i && f.name.find(only) == std::string::npos) continue;
+        g_votes = 0;
         const Result r = run_form(bs, f, (const float *) db.data(), nrays, nrefl, src);
         if (i == 0) { base_cost = r.cost; base_sum = r.checksum; base_bounces = r.bounces; }
         printf("%-44s | ray node %5.2f leaf %4.2f | wave node %5.2f leaf %5.2f done %4.2f per %2d ray-bounces | lanes in step: node %.2f leaf %.2f done %.2f | "
@@ -346,6 +361,7 @@ int main(int argc, char ** argv)
                f.name.c_str(), r.ray_node, r.ray_leaf, r.wave_node, r.wave_leaf, r.wave_done, f.rays_per_wave,
                r.act_node / f.rays_per_wave, r.act_leaf / f.rays_per_wave, r.act_done / f.rays_per_wave, r.cost, 100.0 * (r.cost / base_cost - 1.0),
                (r.checksum == base_sum && r.bounces == base_bounces) ? "" : "  ** HITS DIFFER FROM THE BASELINE FORM **");
+        printf("%-44s | votes %5.2f per %d ray-bounces%s\n", "", (double) g_votes * f.rays_per_wave / (double) r.bounces, f.rays_per_wave, g_chain ? " (TRAVFORMS_CHAIN: node step behind every leaf / shading step)" : "");
         fflush(stdout);
     }
     return 0;
