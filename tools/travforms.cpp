@@ -205,6 +205,7 @@ struct Result { double ray_node, ray_leaf, wave_node, wave_leaf, wave_done, act_
 // one wave runs its rays for up to `bounces_here` bounces each (vote loop of traverse_pairs_vote)
 static unsigned long long g_votes = 0;
 static const bool g_chain = getenv("TRAVFORMS_CHAIN") != nullptr;
+static const int g_double = getenv("TRAVFORMS_DOUBLE") ? atoi(getenv("TRAVFORMS_DOUBLE")) : 0;
 static void run_wave(Sim & s, std::vector<RayState *> & rays, uint32_t stop_bounce, uint32_t nrefl, unsigned long long cnt[3], unsigned long long act[3],
                      unsigned long long & bounces, unsigned long long & checksum)
 {
@@ -223,10 +224,12 @@ static void run_wave(Sim & s, std::vector<RayState *> & rays, uint32_t stop_boun
         if (!(c[0] >= c[1] && c[0] >= c[2])) a = c[1] >= c[2] ? LEAF : DONE;
         ++cnt[a]; act[a] += c[a];
         ++g_votes;
+        const bool strong = a == NODE && g_double > 0 && c[0] * 100 >= g_double * (c[0] + c[1] + c[2]);
         for (int pass = 0; pass < 2; ++pass) {
         if (pass == 1) {
-            // TRAVFORMS_CHAIN=1: a leaf or shading step is followed by a node step for the lanes that are at a node by then, without a vote
-            if (!g_chain || a == NODE) break;
+            // TRAVFORMS_CHAIN=1: a leaf or shading step is followed by a node step for the lanes that are at a node by then, without a vote;
+            // TRAVFORMS_DOUBLE=P: a node step voted for by P % of the live lanes or more is followed by a second one without a vote
+            if (!((g_chain && a != NODE) || strong)) break;
             a = NODE;
             int at_node = 0;
             for (int i = 0; i < nq; ++i) at_node += st[i] == NODE;
