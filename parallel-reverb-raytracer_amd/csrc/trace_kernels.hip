@@ -470,6 +470,9 @@ __device__ __forceinline__ void traverse_jobs_vote(const SceneDev & sc, uint32_t
 #endif
 #if RVB_PAIR_CHAIN
         // (as in traverse_pairs_vote: a leaf or shading step is followed by a node step without a vote in between)
+#if RVB_PAIR_SHORT_VOTE
+        if (2 * n_node < n_active)                 // (the other two counts exist on this path only: the short path goes straight to the node step)
+#endif
         if (!(n_node >= n_leaf && n_node >= n_done)) {
             if (n_leaf >= n_done) {
                 if ((int32_t) ref < (int32_t) IDLE) {
@@ -748,6 +751,9 @@ __device__ __forceinline__ void traverse_pairs_vote(const SceneDev & sc, uint32_
         // A leaf or shading step is FOLLOWED by a node step, without a vote in between: the lanes it served are at a node afterwards (a popped
         // entry, the root of the next bounce) together with those that were waiting for one.  tools/travforms.cpp (TRAVFORMS_CHAIN) replays the
         // same number of wave steps of every kind — 28.6 node, 5.2 leaf, 2.6 shading per 32 ray-bounces — with 28.7 votes instead of 36.2.
+#if RVB_PAIR_SHORT_VOTE
+        if (2 * n_node < n_active)                 // (the other two counts exist on this path only: the short path goes straight to the node step)
+#endif
         if (!(n_node >= n_leaf && n_node >= n_done)) {
             if (n_leaf >= n_done) {
                 RVB_MARK("leaf");
