@@ -41,12 +41,6 @@
 #ifndef RVB_SHADOW_JOBS
 #define RVB_SHADOW_JOBS 0
 #endif
-#ifndef RVB_PAIR_CHAIN
-#define RVB_PAIR_CHAIN 1           // the vote loops: a leaf or shading step is followed by a node step without a vote in between
-#endif
-#ifndef RVB_PAIR_SHORT_VOTE
-#define RVB_PAIR_SHORT_VOTE 1      // the vote loops' short form (traverse_pairs_vote, traverse_jobs_vote): one ballot when the lanes at a node are a majority
-#endif
 #ifndef RVB_LDS_NODES
 #define RVB_LDS_NODES 0        // experiment: top nodes of the BVH staged in LDS per workgroup (path_kernel); 21 = levels 0-2
 #endif
@@ -443,11 +437,8 @@ __device__ __forceinline__ void traverse_jobs_vote(const SceneDev & sc, uint32_t
         best_key = NO_HIT_KEY; sp = 0; ref = 0;                                   \
     }
     if (job.next(o, d, tmax)) RVB_RESET_QUERY()
-#if RVB_PAIR_SHORT_VOTE
     int n_active = scalar_popcount(__builtin_amdgcn_ballot_w64(ref != IDLE));      // lanes that carry a ray: changes in shading steps only
-#endif
     for (;;) {
-#if RVB_PAIR_SHORT_VOTE
         // the short form of the vote (traverse_pairs_vote): lanes at a node that are half of the live lanes or more ARE the largest group.
         // Alone at 100 k rays 3.54 -> 3.31 ms (profiles/r04c_short_vote_quads_n1.txt).  The pair loop's other changes — signed keys built
         // with v_bitop3, the culling distance as state, the winner's reference by two DPP ORs instead of ds_bpermute — change nothing
@@ -460,19 +451,8 @@ __device__ __forceinline__ void traverse_jobs_vote(const SceneDev & sc, uint32_t
             n_done = scalar_popcount(__builtin_amdgcn_ballot_w64(ref == NONE));
             n_leaf = scalar_popcount(__builtin_amdgcn_ballot_w64((int32_t) ref < (int32_t) IDLE));   // signed: leaves are < -2
         }
-#else
-        const unsigned long long m_node = __builtin_amdgcn_ballot_w64((int32_t) ref >= 0);
-        const unsigned long long m_done = __builtin_amdgcn_ballot_w64(ref == NONE);
-        const unsigned long long m_leaf = __builtin_amdgcn_ballot_w64((int32_t) ref < (int32_t) IDLE);   // signed: leaves are < -2
-        const int n_node = scalar_popcount(m_node), n_done = scalar_popcount(m_done), n_leaf = scalar_popcount(m_leaf);
-        if ((n_node | n_done | n_leaf) == 0)
-            break;
-#endif
-#if RVB_PAIR_CHAIN
         // (as in traverse_pairs_vote: a leaf or shading step is followed by a node step without a vote in between)
-#if RVB_PAIR_SHORT_VOTE
         if (2 * n_node < n_active)                 // (the other two counts exist on this path only: the short path goes straight to the node step)
-#endif
         if (!(n_node >= n_leaf && n_node >= n_done)) {
             if (n_leaf >= n_done) {
                 if ((int32_t) ref < (int32_t) IDLE) {
@@ -507,9 +487,7 @@ __device__ __forceinline__ void traverse_jobs_vote(const SceneDev & sc, uint32_t
                     ref = IDLE;
                     if (job.next(o, d, tmax)) RVB_RESET_QUERY()
                 }
-#if RVB_PAIR_SHORT_VOTE
                 n_active = scalar_popcount(__builtin_amdgcn_ballot_w64(ref != IDLE));
-#endif
             }
         }
         {
@@ -544,76 +522,6 @@ __device__ __forceinline__ void traverse_jobs_vote(const SceneDev & sc, uint32_t
             }
         }
     }
-#else
-        if (n_node >= n_leaf && n_node >= n_done) {
-            if ((int32_t) ref >= 0) {
-#if RVB_LDS_NODES
-                uint4 n;
-                if (ref < RVB_LDS_NODES * 64u) { const nt_float4 t = lds_nodes[(ref | child_off) >> 4]; n = make_uint4(__float_as_uint(t.x), __float_as_uint(t.y), __float_as_uint(t.z), __float_as_uint(t.w)); }
-                else n = *reinterpret_cast<const uint4 *>(node_base + (ref | child_off));
-#else
-                const uint4 n = *reinterpret_cast<const uint4 *>(node_base + (ref | child_off));
-#endif
-                const float limit = fmaf(__uint_as_float((uint32_t) (best_key >> 32)), cull_scale, sc.cull_abs);
-                float tn;
-                const bool ok = RVB_QUAD_SLAB(n, tn);
-                const uint32_t cref = n.w;
-                const uint32_t key = ok ? ((__float_as_uint(fmaxf(tn, 0.0f)) & ~3u) | c) : NONE;
-                uint32_t kmin = min(key, dpp_u<QP_SWAP1>(key));
-                kmin = min(kmin, dpp_u<QP_SWAP2>(kmin));
-                if (kmin == NONE) {
-                    if (sp > 0) { --sp; ref = stack[sp * QUADS_PER_BLOCK]; } else ref = NONE;
-                } else {
-                    const uint32_t winner = kmin & 3u;
-                    uint32_t okmask = ok ? lane_bit : 0u;
-                    okmask |= dpp_u<QP_SWAP1>(okmask);
-                    okmask |= dpp_u<QP_SWAP2>(okmask);
-                    const uint32_t rest = okmask & ~(1u << winner);
-                    if (ok && c != winner)
-                        stack[(sp + __popc(rest & lt_mask)) * QUADS_PER_BLOCK] = cref;
-                    sp += __popc(rest);
-                    ref = (uint32_t) __builtin_amdgcn_ds_bpermute((int) (lane_base4 + (winner << 2)), (int) cref);
-                }
-            }
-        } else if (n_leaf >= n_done) {
-            if ((int32_t) ref < (int32_t) IDLE) {
-                const uint32_t first = ref & 0x0FFFFFFFu;
-                const uint32_t count = ((ref >> 28) & 7u) + 1u;
-                float dist = 0.0f;
-                uint32_t idx = NONE;
-                if (c < count) {
-                    const float4 * tp = reinterpret_cast<const float4 *>(tri_base + tri_byte_offset(first + c));
-                    float4 ta = tp[0], tb = tp[1], tc = tp[2];
-                    asm volatile("" : "+v"(ta.x), "+v"(tb.x), "+v"(tc.x));     // all three loads leave before the first use
-                    dist = mt_intersect(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), o, d);
-                    idx = __float_as_uint(tc.y);
-                }
-                // kernel.cpp:180-188 — smallest distance wins, equal distances go to the lower index.  A candidate
-                // distance is > EPSILON > 0, and positive floats order like their bit patterns, so (distance, index)
-                // is ONE unsigned 64-bit key: the quad minimum and the comparison with the best so far are three
-                // 64-bit compares.  "No hit" is (+inf, NONE), the largest key a lane can hold.
-                const bool valid = c < count && dist > RVB_EPSILON;
-                unsigned long long key = valid ? (((unsigned long long) __float_as_uint(dist) << 32) | idx) : NO_HIT_KEY;
-                key = min_u64(key, dpp_u64<QP_SWAP1>(key));
-                key = min_u64(key, dpp_u64<QP_SWAP2>(key));
-                best_key = min_u64(best_key, key);
-                if (sp > 0) { --sp; ref = stack[sp * QUADS_PER_BLOCK]; } else ref = NONE;
-            }
-        } else {
-            if (ref == NONE) {
-                Hit h;
-                h.t = __uint_as_float((uint32_t) (best_key >> 32));
-                h.tri = (uint32_t) best_key;
-                job.done(h.tri != NONE, h);
-                ref = IDLE;
-                if (job.next(o, d, tmax)) RVB_RESET_QUERY()
-            }
-#if RVB_PAIR_SHORT_VOTE
-            n_active = scalar_popcount(__builtin_amdgcn_ballot_w64(ref != IDLE));
-#endif
-        }
-    }
-#endif
 #undef RVB_RESET_QUERY
 }
 
@@ -627,7 +535,9 @@ __device__ __forceinline__ void traverse_jobs_vote(const SceneDev & sc, uint32_t
 #define RVB_PAIR_SELECT 1          // bit 0: path_pair_kernel, bit 1: shadow_pair_kernel use slab_select (near / far plane by the direction's sign)
                                    // instead of slab (min / max).  Measured at C2: path pairs 3.92 -> 3.80 ms, shadow pairs 1.28 -> 1.34 ms
 #endif
-// RVB_PAIR_PUSH_COUNTS = 1 (round 4): the node step of traverse_pairs_vote written for ISSUE COST.  In the pipeline (traces of the
+// The node step of traverse_pairs_vote is written for ISSUE COST (round 4; measured as the build flag RVB_PAIR_PUSH_COUNTS against the
+// hit-mask form it replaced, like the short vote — RVB_PAIR_SHORT_VOTE — and the chained node step — RVB_PAIR_CHAIN — further down: the
+// flags were folded in once the measurements were committed, tools/r04*_*.sh name them).  In the pipeline (traces of the
 // next group beside the binning of this one) the SIMDs issue vector instructions three quarters of the time, and the node step is two
 // thirds of the path kernel's instructions; tools/inst_probe.hip measures two classes of them on gfx950 — v_fma / v_add / v_mul_f32,
 // v_mov, two-operand integer add / and / or / xor / right shift and v_bitop3 issue at the full rate, everything else (comparisons,
@@ -643,9 +553,6 @@ __device__ __forceinline__ void traverse_jobs_vote(const SceneDev & sc, uint32_t
 // VGPRs (RVB_PAIR_WAVES = 6); uncapped it takes 84, loses a wave per SIMD to the kernels beside it and the pipeline is 8 % SLOWER
 // (4.82-4.87 ms) — the register count of the path kernel matters more than its instruction count.  Alone (one trace of 100 k rays,
 // bound by the latency of its chains) the kernel takes 3.49 ms either way.
-#ifndef RVB_PAIR_PUSH_COUNTS
-#define RVB_PAIR_PUSH_COUNTS 1
-#endif
 #define RVB_PAIR_SLAB(SEL, n, tn, skip) ((SEL) ? slab_select(n, ix, iy, iz, oix, oiy, oiz, selx, sely, selz, limit, neg_cull, skip, tn) \
                                                : slab(n, ix, iy, iz, oix, oiy, oiz, limit, neg_cull, skip, tn))
 template <class Job>
@@ -656,9 +563,6 @@ __device__ __forceinline__ void traverse_pairs_vote(const SceneDev & sc, uint32_
     const uint32_t h = threadIdx.x & 1u;
     uint32_t c0 = 2u * h, c1 = c0 + 1u;                                    // the children this lane owns
     asm volatile("" : "+v"(c0), "+v"(c1));                                 // lane constants that stay in their registers (else recomputed in every node step)
-#if !RVB_PAIR_PUSH_COUNTS
-    const uint32_t bit0 = 1u << c0, bit1 = 2u << c0, lt0 = bit0 - 1u, lt1 = bit1 - 1u;
-#endif
     const char * node_base = reinterpret_cast<const char *>(sc.nodes);
     const char * tri_base = reinterpret_cast<const char *>(sc.tris);
     uint32_t child_off = 32u * h;
@@ -671,7 +575,6 @@ __device__ __forceinline__ void traverse_pairs_vote(const SceneDev & sc, uint32_
     float tmax = 0.0f;
     float ix = 0.0f, iy = 0.0f, iz = 0.0f, oix = 0.0f, oiy = 0.0f, oiz = 0.0f;
     unsigned long long best_key = NO_HIT_KEY;
-#if RVB_PAIR_PUSH_COUNTS
     // the stack pointer is the LDS byte address of the pair's next free row (rows are PAIRS_PER_BLOCK words apart)
     const uint32_t PAIR_ROW = PAIRS_PER_BLOCK * (uint32_t) sizeof(uint32_t);
     const uint32_t bottom = (uint32_t) (uintptr_t) (lds_u32_ptr) stack;
@@ -681,19 +584,9 @@ __device__ __forceinline__ void traverse_pairs_vote(const SceneDev & sc, uint32_
 #define sp walk.y
 #define RVB_PAIR_POP() { if (sp != bottom) { sp -= PAIR_ROW; ref = *(lds_u32_ptr) (uintptr_t) sp; } else ref = NONE; }
 #define RVB_PAIR_EMPTY() sp = bottom
-#else
-    uint32_t sp = 0;
-#define RVB_PAIR_POP() { if (sp > 0) { --sp; ref = stack[sp * PAIRS_PER_BLOCK]; } else ref = NONE; }
-#define RVB_PAIR_EMPTY() sp = 0
-    uint32_t ref = IDLE;
-#endif
     uint32_t selx = 0, sely = 0, selz = 0;
-#if RVB_PAIR_PUSH_COUNTS
     float limit = 0.0f;                  // culling distance of the best hit so far: changes in leaf steps, is read in node steps
 #define RVB_PAIR_LIMIT() limit = fmaf(__uint_as_float((uint32_t) (best_key >> 32)), cull_scale, sc.cull_abs)
-#else
-#define RVB_PAIR_LIMIT()
-#endif
 #define RVB_RESET_QUERY()                                                         \
     {                                                                             \
         ix = clamp_inv(d.x); iy = clamp_inv(d.y); iz = clamp_inv(d.z);            \
@@ -712,13 +605,10 @@ __device__ __forceinline__ void traverse_pairs_vote(const SceneDev & sc, uint32_
     t_c = t_loop;
 #endif
     if (job.next(o, d, tmax)) RVB_RESET_QUERY()
-#if RVB_PAIR_SHORT_VOTE
     // lanes that carry a ray (not IDLE): changes in shading steps only
     int n_active = scalar_popcount(__builtin_amdgcn_ballot_w64(ref != IDLE));
-#endif
     for (;;) {
         RVB_MARK("vote");
-#if RVB_PAIR_SHORT_VOTE
         // The vote, short form: a wave's time goes into the LATENCY of its instructions (a dependent scalar chain behind three ballots is
         // 300 of an iteration's 1 900 cycles, tools/pair_stamps.py), and four iterations in five are node steps.  When the lanes at a node
         // are half of the live lanes or more they are the largest group whatever the other two counts are: those are then not formed.
@@ -735,25 +625,14 @@ __device__ __forceinline__ void traverse_pairs_vote(const SceneDev & sc, uint32_
             n_done = scalar_popcount(__builtin_amdgcn_ballot_w64(ref == NONE));
             n_leaf = scalar_popcount(__builtin_amdgcn_ballot_w64((int32_t) ref < (int32_t) IDLE));
         }
-#else
-        const unsigned long long m_node = __builtin_amdgcn_ballot_w64((int32_t) ref >= 0);
-        const unsigned long long m_done = __builtin_amdgcn_ballot_w64(ref == NONE);
-        const unsigned long long m_leaf = __builtin_amdgcn_ballot_w64((int32_t) ref < (int32_t) IDLE);
-        const int n_node = scalar_popcount(m_node), n_done = scalar_popcount(m_done), n_leaf = scalar_popcount(m_leaf);
-        if ((n_node | n_done | n_leaf) == 0)
-            break;
-#endif
 #if RVB_STAMPS == 1
         STAMP(t_a)
         sv[0] += t_a - t_c;
 #endif
-#if RVB_PAIR_CHAIN
         // A leaf or shading step is FOLLOWED by a node step, without a vote in between: the lanes it served are at a node afterwards (a popped
         // entry, the root of the next bounce) together with those that were waiting for one.  tools/travforms.cpp (TRAVFORMS_CHAIN) replays the
         // same number of wave steps of every kind — 28.6 node, 5.2 leaf, 2.6 shading per 32 ray-bounces — with 28.7 votes instead of 36.2.
-#if RVB_PAIR_SHORT_VOTE
         if (2 * n_node < n_active)                 // (the other two counts exist on this path only: the short path goes straight to the node step)
-#endif
         if (!(n_node >= n_leaf && n_node >= n_done)) {
             if (n_leaf >= n_done) {
                 RVB_MARK("leaf");
@@ -803,9 +682,7 @@ __device__ __forceinline__ void traverse_pairs_vote(const SceneDev & sc, uint32_
                     ref = IDLE;
                     if (job.next(o, d, tmax)) RVB_RESET_QUERY()
                 }
-#if RVB_PAIR_SHORT_VOTE
                 n_active = scalar_popcount(__builtin_amdgcn_ballot_w64(ref != IDLE));
-#endif
 #if RVB_STAMPS == 1
                 STAMP(t_c)
                 sv[5] += t_c - t_a; sn[2] += 1;
@@ -839,13 +716,9 @@ __device__ __forceinline__ void traverse_pairs_vote(const SceneDev & sc, uint32_
                 const uint4 * np = reinterpret_cast<const uint4 *>(node_base + (ref | child_off));
                 const uint4 n0 = np[0], n1 = np[1];
 #endif
-#if !RVB_PAIR_PUSH_COUNTS
-                const float limit = fmaf(__uint_as_float((uint32_t) (best_key >> 32)), cull_scale, sc.cull_abs);
-#endif
                 float tn0, tn1;
                 const bool ok0 = RVB_PAIR_SLAB(RVB_PAIR_SELECT & 1, n0, tn0, job.skip_ref());
                 const bool ok1 = RVB_PAIR_SLAB(RVB_PAIR_SELECT & 1, n1, tn1, job.skip_ref());
-#if RVB_PAIR_PUSH_COUNTS
                 // the hit children's keys: entry distance (its two low bits give way to the child number), compared as SIGNED integers —
                 // negative distances (the origin is inside the box, or the box a rounding behind it) come before all others, in any
                 // order; tools/travforms.cpp replays the same number of node visits as with keys of max(distance, 0)
@@ -857,16 +730,8 @@ __device__ __forceinline__ void traverse_pairs_vote(const SceneDev & sc, uint32_
                 uint32_t kmin = (uint32_t) min((int32_t) key0, (int32_t) key1);
                 kmin = (uint32_t) min((int32_t) kmin, (int32_t) dpp_u<QP_SWAP1>(kmin));
                 if (kmin == NO_CHILD) {
-#else
-                const uint32_t key0 = ok0 ? ((__float_as_uint(fmaxf(tn0, 0.0f)) & ~3u) | c0) : NONE;
-                const uint32_t key1 = ok1 ? ((__float_as_uint(fmaxf(tn1, 0.0f)) & ~3u) | c1) : NONE;
-                uint32_t kmin = min(key0, key1);
-                kmin = min(kmin, dpp_u<QP_SWAP1>(kmin));
-                if (kmin == NONE) {
-#endif
                     RVB_PAIR_POP()
                 } else {
-#if RVB_PAIR_PUSH_COUNTS
                     // the pair's pushes in child order (as below) from the lanes' COUNTS: a lane's kept children go on top of the other
                     // lane's if it is the pair's second lane, so one 2-bit count crosses the pair instead of the hit mask, and a lane's
                     // rows follow from its own two flags (the keys name the child: key == kmin is the winner)
@@ -884,20 +749,6 @@ __device__ __forceinline__ void traverse_pairs_vote(const SceneDev & sc, uint32_
                     const uint32_t mine = other1 ? (other0 ? 0u : n0.w) : n1.w;            // 0 in the lane that does not own it
                     sp += n_mine + n_theirs;
                     ref = mine | dpp_u<QP_SWAP1>(mine);
-#else
-                    const uint32_t winner = kmin & 3u;
-                    uint32_t okmask = (ok0 ? bit0 : 0u) | (ok1 ? bit1 : 0u);
-                    okmask |= dpp_u<QP_SWAP1>(okmask);
-                    const uint32_t rest = okmask & ~(1u << winner);
-                    if (ok0 && c0 != winner)
-                        stack[(sp + __popc(rest & lt0)) * PAIRS_PER_BLOCK] = n0.w;
-                    if (ok1 && c1 != winner)
-                        stack[(sp + __popc(rest & lt1)) * PAIRS_PER_BLOCK] = n1.w;
-                    sp += __popc(rest);
-                    const uint32_t mine = (winner & 1u) ? n1.w : n0.w;
-                    const uint32_t theirs = dpp_u<QP_SWAP1>(mine);
-                    ref = (winner >> 1) == h ? mine : theirs;
-#endif
                 }
             }
 #if RVB_STAMPS == 1
@@ -907,159 +758,6 @@ __device__ __forceinline__ void traverse_pairs_vote(const SceneDev & sc, uint32_
         }
         RVB_MARK("loop_end");
     }
-#else
-        if (n_node >= n_leaf && n_node >= n_done) {
-            RVB_MARK("node");
-#if RVB_STAMPS == 1
-            if ((int32_t) ref >= 0) {
-                const uint4 * pp = reinterpret_cast<const uint4 *>(node_base + (ref | child_off));
-                uint4 w0 = pp[0], w1 = pp[1];
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0.x), "+v"(w1.x) :: "memory");     // the step's own loads hit the L1 afterwards
-            }
-            STAMP(t_b)
-            sv[1] += t_b - t_a; sn[0] += 1;
-#endif
-            if ((int32_t) ref >= 0) {
-#if RVB_LDS_NODES
-                uint4 n0, n1;
-                if (ref < RVB_LDS_NODES * 64u) {
-                    const nt_float4 t0 = lds_nodes[(ref | child_off) >> 4], t1 = lds_nodes[((ref | child_off) >> 4) + 1];
-                    n0 = make_uint4(__float_as_uint(t0.x), __float_as_uint(t0.y), __float_as_uint(t0.z), __float_as_uint(t0.w));
-                    n1 = make_uint4(__float_as_uint(t1.x), __float_as_uint(t1.y), __float_as_uint(t1.z), __float_as_uint(t1.w));
-                } else {
-                    const uint4 * np = reinterpret_cast<const uint4 *>(node_base + (ref | child_off));
-                    n0 = np[0]; n1 = np[1];
-                }
-#else
-                const uint4 * np = reinterpret_cast<const uint4 *>(node_base + (ref | child_off));
-                const uint4 n0 = np[0], n1 = np[1];
-#endif
-#if !RVB_PAIR_PUSH_COUNTS
-                const float limit = fmaf(__uint_as_float((uint32_t) (best_key >> 32)), cull_scale, sc.cull_abs);
-#endif
-                float tn0, tn1;
-                const bool ok0 = RVB_PAIR_SLAB(RVB_PAIR_SELECT & 1, n0, tn0, job.skip_ref());
-                const bool ok1 = RVB_PAIR_SLAB(RVB_PAIR_SELECT & 1, n1, tn1, job.skip_ref());
-#if RVB_PAIR_PUSH_COUNTS
-                // the hit children's keys: entry distance (its two low bits give way to the child number), compared as SIGNED integers —
-                // negative distances (the origin is inside the box, or the box a rounding behind it) come before all others, in any
-                // order; tools/travforms.cpp replays the same number of node visits as with keys of max(distance, 0)
-                const uint32_t NO_CHILD = 0x7FFFFFFFu;
-                // ((distance & ~3) | child) as one v_bitop3_b32 with register operands: issues at the rate of v_fma_f32, the and_or
-                // form at 0.6 of it (profiles/r04b_inst_probe.log)
-                const uint32_t key0 = ok0 ? __builtin_amdgcn_bitop3_b32(__float_as_uint(tn0), clear2, c0, 0xEA) : NO_CHILD;
-                const uint32_t key1 = ok1 ? __builtin_amdgcn_bitop3_b32(__float_as_uint(tn1), clear2, c1, 0xEA) : NO_CHILD;
-                uint32_t kmin = (uint32_t) min((int32_t) key0, (int32_t) key1);
-                kmin = (uint32_t) min((int32_t) kmin, (int32_t) dpp_u<QP_SWAP1>(kmin));
-                if (kmin == NO_CHILD) {
-#else
-                const uint32_t key0 = ok0 ? ((__float_as_uint(fmaxf(tn0, 0.0f)) & ~3u) | c0) : NONE;
-                const uint32_t key1 = ok1 ? ((__float_as_uint(fmaxf(tn1, 0.0f)) & ~3u) | c1) : NONE;
-                uint32_t kmin = min(key0, key1);
-                kmin = min(kmin, dpp_u<QP_SWAP1>(kmin));
-                if (kmin == NONE) {
-#endif
-                    RVB_PAIR_POP()
-                } else {
-#if RVB_PAIR_PUSH_COUNTS
-                    // the pair's pushes in child order (as below) from the lanes' COUNTS: a lane's kept children go on top of the other
-                    // lane's if it is the pair's second lane, so one 2-bit count crosses the pair instead of the hit mask, and a lane's
-                    // rows follow from its own two flags (the keys name the child: key == kmin is the winner)
-                    const bool other0 = key0 != kmin, other1 = key1 != kmin;
-                    const bool keep0 = ok0 && other0, keep1 = ok1 && other1;
-                    const uint32_t first = keep0 ? PAIR_ROW : 0u;                          // counts in bytes of stack rows
-                    const uint32_t n_mine = first + (keep1 ? PAIR_ROW : 0u);
-                    const uint32_t n_theirs = dpp_u<QP_SWAP1>(n_mine);
-                    const uint32_t row = __umul24(n_theirs, h) + sp;                       // sp + (h ? n_theirs : 0) as one v_mad_u32_u24
-                    if (keep0)
-                        *(lds_u32_ptr) (uintptr_t) row = n0.w;
-                    if (keep1)
-                        *(lds_u32_ptr) (uintptr_t) (row + first) = n1.w;
-                    // the winner is the child whose key IS kmin (keys carry the child number)
-                    const uint32_t mine = other1 ? (other0 ? 0u : n0.w) : n1.w;            // 0 in the lane that does not own it
-                    sp += n_mine + n_theirs;
-                    ref = mine | dpp_u<QP_SWAP1>(mine);
-#else
-                    const uint32_t winner = kmin & 3u;
-                    uint32_t okmask = (ok0 ? bit0 : 0u) | (ok1 ? bit1 : 0u);
-                    okmask |= dpp_u<QP_SWAP1>(okmask);
-                    const uint32_t rest = okmask & ~(1u << winner);
-                    if (ok0 && c0 != winner)
-                        stack[(sp + __popc(rest & lt0)) * PAIRS_PER_BLOCK] = n0.w;
-                    if (ok1 && c1 != winner)
-                        stack[(sp + __popc(rest & lt1)) * PAIRS_PER_BLOCK] = n1.w;
-                    sp += __popc(rest);
-                    const uint32_t mine = (winner & 1u) ? n1.w : n0.w;
-                    const uint32_t theirs = dpp_u<QP_SWAP1>(mine);
-                    ref = (winner >> 1) == h ? mine : theirs;
-#endif
-                }
-            }
-#if RVB_STAMPS == 1
-            STAMP(t_c)
-            sv[2] += t_c - t_b;
-#endif
-            continue;
-        } else if (n_leaf >= n_done) {
-            RVB_MARK("leaf");
-#if RVB_STAMPS == 1
-            if ((int32_t) ref < (int32_t) IDLE) {
-                const uint32_t first = ref & 0x0FFFFFFFu, count = ((ref >> 28) & 7u) + 1u;
-                const float4 * q0 = reinterpret_cast<const float4 *>(tri_base + tri_byte_offset(first + (h < count ? h : 0u)));
-                const float4 * q1 = reinterpret_cast<const float4 *>(tri_base + tri_byte_offset(first + (h + 2u < count ? h + 2u : 0u)));
-                float4 w0 = q0[0], w1 = q0[2], w2 = q1[0], w3 = q1[2];
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0.x), "+v"(w1.x), "+v"(w2.x), "+v"(w3.x) :: "memory");
-            }
-            STAMP(t_b)
-            sv[3] += t_b - t_a; sn[1] += 1;
-#endif
-            if ((int32_t) ref < (int32_t) IDLE) {
-                // triangles h and h + 2 of the leaf (a two-triangle leaf gives each lane one)
-                const uint32_t first = ref & 0x0FFFFFFFu;
-                const uint32_t count = ((ref >> 28) & 7u) + 1u;
-                const uint32_t j0 = h, j1 = h + 2u;
-                const float4 * tp0 = reinterpret_cast<const float4 *>(tri_base + tri_byte_offset(first + (j0 < count ? j0 : 0u)));
-                const float4 * tp1 = reinterpret_cast<const float4 *>(tri_base + tri_byte_offset(first + (j1 < count ? j1 : 0u)));
-                float4 ta = tp0[0], tb = tp0[1], tc = tp0[2], ua = tp1[0], ub = tp1[1], uc = tp1[2];
-                asm volatile("" : "+v"(ta.x), "+v"(tb.x), "+v"(tc.x), "+v"(ua.x), "+v"(ub.x), "+v"(uc.x));   // all six loads leave before the first use
-                const float dist0 = mt_intersect(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), o, d);
-                const float dist1 = mt_intersect(mk3(ua.x, ua.y, ua.z), mk3(ua.w, ub.x, ub.y), mk3(ub.z, ub.w, uc.x), o, d);
-                // kernel.cpp:180-188 — smallest distance wins, equal distances go to the lower index: one unsigned 64-bit key
-                const bool valid0 = j0 < count && dist0 > RVB_EPSILON, valid1 = j1 < count && dist1 > RVB_EPSILON;
-                const unsigned long long k0 = valid0 ? (((unsigned long long) __float_as_uint(dist0) << 32) | __float_as_uint(tc.y)) : NO_HIT_KEY;
-                const unsigned long long k1 = valid1 ? (((unsigned long long) __float_as_uint(dist1) << 32) | __float_as_uint(uc.y)) : NO_HIT_KEY;
-                unsigned long long key = min_u64(k0, k1);
-                key = min_u64(key, dpp_u64<QP_SWAP1>(key));
-                best_key = min_u64(best_key, key);
-                RVB_PAIR_LIMIT();
-                RVB_PAIR_POP()
-            }
-#if RVB_STAMPS == 1
-            STAMP(t_c)
-            sv[4] += t_c - t_b;
-#endif
-            continue;
-        } else {
-            RVB_MARK("done");
-            if (ref == NONE) {
-                Hit hit;
-                hit.t = __uint_as_float((uint32_t) (best_key >> 32));
-                hit.tri = (uint32_t) best_key;
-                job.done(hit.tri != NONE, hit);
-                ref = IDLE;
-                if (job.next(o, d, tmax)) RVB_RESET_QUERY()
-            }
-#if RVB_PAIR_SHORT_VOTE
-            n_active = scalar_popcount(__builtin_amdgcn_ballot_w64(ref != IDLE));
-#endif
-        }
-#if RVB_STAMPS == 1
-        STAMP(t_c)
-        sv[5] += t_c - t_a; sn[2] += 1;
-#endif
-        RVB_MARK("loop_end");
-    }
-#endif
 #if RVB_STAMPS
     if (sc.stamps) {
         STAMP(t_b)
@@ -1077,10 +775,8 @@ __device__ __forceinline__ void traverse_pairs_vote(const SceneDev & sc, uint32_
 #undef RVB_RESET_QUERY
 #undef RVB_PAIR_POP
 #undef RVB_PAIR_EMPTY
-#if RVB_PAIR_PUSH_COUNTS
 #undef ref
 #undef sp
-#endif
 #undef RVB_PAIR_LIMIT
 }
 
@@ -1446,7 +1142,7 @@ __global__ __launch_bounds__(WAVE, WAVES) void path_kernel(TraceArgs a)
 
 // path_kernel with two lanes per ray (traverse_pairs_vote): 32 rays per single-wave workgroup.
 #ifndef RVB_PAIR_WAVES
-#define RVB_PAIR_WAVES 6            // register cap: 80 VGPRs, so that six waves fit a SIMD beside the other kernels' (see RVB_PAIR_PUSH_COUNTS);
+#define RVB_PAIR_WAVES 6            // register cap: 80 VGPRs, so that six waves fit a SIMD beside the other kernels' (see the node step of traverse_pairs_vote);
                                     // 7 (72 VGPRs) spills ten registers: pipeline 4.52-4.54 ms against 4.37-4.40, and 4.70 against 4.47 when LDS
                                     // allows the seventh wave too (no key runs: profiles/r04c_occupancy_n1.txt); 8 (64 VGPRs): 5.9 ms
 #endif
