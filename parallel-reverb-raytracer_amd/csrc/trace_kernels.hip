@@ -41,6 +41,14 @@
 #ifndef RVB_SHADOW_JOBS
 #define RVB_SHADOW_JOBS 0
 #endif
+#ifndef RVB_CYCLE_LEAF_NUM
+#define RVB_CYCLE_LEAF_NUM 3       // a leaf step when NUM x (lanes at a leaf) >= DEN x (live lanes)
+#define RVB_CYCLE_LEAF_DEN 1
+#endif
+#ifndef RVB_CYCLE_DONE_NUM
+#define RVB_CYCLE_DONE_NUM 4       // a shading step when NUM x (lanes with a finished query) >= DEN x (live lanes)
+#define RVB_CYCLE_DONE_DEN 1
+#endif
 #ifndef RVB_LDS_NODES
 #define RVB_LDS_NODES 0        // experiment: top nodes of the BVH staged in LDS per workgroup (path_kernel); 21 = levels 0-2
 #endif
@@ -437,90 +445,89 @@ __device__ __forceinline__ void traverse_jobs_vote(const SceneDev & sc, uint32_t
         best_key = NO_HIT_KEY; sp = 0; ref = 0;                                   \
     }
     if (job.next(o, d, tmax)) RVB_RESET_QUERY()
-    int n_active = scalar_popcount(__builtin_amdgcn_ballot_w64(ref != IDLE));      // lanes that carry a ray: changes in shading steps only
+    int n_active = 0;                    // lanes that carry a ray (not IDLE): changes in shading steps only
+    auto leaf_step = [&]() {
+        if ((int32_t) ref < (int32_t) IDLE) {
+            const uint32_t first = ref & 0x0FFFFFFFu;
+            const uint32_t count = ((ref >> 28) & 7u) + 1u;
+            float dist = 0.0f;
+            uint32_t idx = NONE;
+            if (c < count) {
+                const float4 * tp = reinterpret_cast<const float4 *>(tri_base + tri_byte_offset(first + c));
+                float4 ta = tp[0], tb = tp[1], tc = tp[2];
+                asm volatile("" : "+v"(ta.x), "+v"(tb.x), "+v"(tc.x));     // all three loads leave before the first use
+                dist = mt_intersect(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), o, d);
+                idx = __float_as_uint(tc.y);
+            }
+            // kernel.cpp:180-188 — smallest distance wins, equal distances go to the lower index.  A candidate
+            // distance is > EPSILON > 0, and positive floats order like their bit patterns, so (distance, index)
+            // is ONE unsigned 64-bit key: the quad minimum and the comparison with the best so far are three
+            // 64-bit compares.  "No hit" is (+inf, NONE), the largest key a lane can hold.
+            const bool valid = c < count && dist > RVB_EPSILON;
+            unsigned long long key = valid ? (((unsigned long long) __float_as_uint(dist) << 32) | idx) : NO_HIT_KEY;
+            key = min_u64(key, dpp_u64<QP_SWAP1>(key));
+            key = min_u64(key, dpp_u64<QP_SWAP2>(key));
+            best_key = min_u64(best_key, key);
+            if (sp > 0) { --sp; ref = stack[sp * QUADS_PER_BLOCK]; } else ref = NONE;
+        }
+    };
+    auto shading_step = [&]() {
+        if (ref == NONE) {
+            Hit h;
+            h.t = __uint_as_float((uint32_t) (best_key >> 32));
+            h.tri = (uint32_t) best_key;
+            job.done(h.tri != NONE, h);
+            ref = IDLE;
+            if (job.next(o, d, tmax)) RVB_RESET_QUERY()
+        }
+        n_active = scalar_popcount(__builtin_amdgcn_ballot_w64(ref != IDLE));
+    };
+    auto node_step = [&]() {
+        if ((int32_t) ref >= 0) {
+#if RVB_LDS_NODES
+            uint4 n;
+            if (ref < RVB_LDS_NODES * 64u) { const nt_float4 t = lds_nodes[(ref | child_off) >> 4]; n = make_uint4(__float_as_uint(t.x), __float_as_uint(t.y), __float_as_uint(t.z), __float_as_uint(t.w)); }
+            else n = *reinterpret_cast<const uint4 *>(node_base + (ref | child_off));
+#else
+            const uint4 n = *reinterpret_cast<const uint4 *>(node_base + (ref | child_off));
+#endif
+            const float limit = fmaf(__uint_as_float((uint32_t) (best_key >> 32)), cull_scale, sc.cull_abs);
+            float tn;
+            const bool ok = RVB_QUAD_SLAB(n, tn);
+            const uint32_t cref = n.w;
+            const uint32_t key = ok ? ((__float_as_uint(fmaxf(tn, 0.0f)) & ~3u) | c) : NONE;
+            uint32_t kmin = min(key, dpp_u<QP_SWAP1>(key));
+            kmin = min(kmin, dpp_u<QP_SWAP2>(kmin));
+            if (kmin == NONE) {
+                if (sp > 0) { --sp; ref = stack[sp * QUADS_PER_BLOCK]; } else ref = NONE;
+            } else {
+                const uint32_t winner = kmin & 3u;
+                uint32_t okmask = ok ? lane_bit : 0u;
+                okmask |= dpp_u<QP_SWAP1>(okmask);
+                okmask |= dpp_u<QP_SWAP2>(okmask);
+                const uint32_t rest = okmask & ~(1u << winner);
+                if (ok && c != winner)
+                    stack[(sp + __popc(rest & lt_mask)) * QUADS_PER_BLOCK] = cref;
+                sp += __popc(rest);
+                ref = (uint32_t) __builtin_amdgcn_ds_bpermute((int) (lane_base4 + (winner << 2)), (int) cref);
+            }
+        }
+    };
+    n_active = scalar_popcount(__builtin_amdgcn_ballot_w64(ref != IDLE));
+    // (the schedule of traverse_pairs_vote: no vote — node step, leaf step if a third of the live lanes wait for one, shading step if a quarter do)
     for (;;) {
-        // the short form of the vote (traverse_pairs_vote): lanes at a node that are half of the live lanes or more ARE the largest group.
-        // Alone at 100 k rays 3.54 -> 3.31 ms (profiles/r04c_short_vote_quads_n1.txt).  The pair loop's other changes — signed keys built
-        // with v_bitop3, the culling distance as state, the winner's reference by two DPP ORs instead of ds_bpermute — change nothing
-        // here (3.29-3.36 ms with and without, profiles/r04c_quad_lean_n1.txt) and were not kept.
         if (n_active == 0)
             break;
-        const int n_node = scalar_popcount(__builtin_amdgcn_ballot_w64((int32_t) ref >= 0));
-        int n_done = 0, n_leaf = 0;
-        if (2 * n_node < n_active) {
-            n_done = scalar_popcount(__builtin_amdgcn_ballot_w64(ref == NONE));
-            n_leaf = scalar_popcount(__builtin_amdgcn_ballot_w64((int32_t) ref < (int32_t) IDLE));   // signed: leaves are < -2
+        bool ran = __builtin_amdgcn_ballot_w64((int32_t) ref >= 0) != 0ull;
+        node_step();
+        const int n_leaf = scalar_popcount(__builtin_amdgcn_ballot_w64((int32_t) ref < (int32_t) IDLE));   // signed: leaves are < -2
+        if (n_leaf && (RVB_CYCLE_LEAF_NUM * n_leaf >= RVB_CYCLE_LEAF_DEN * n_active || !ran)) {
+            leaf_step();
+            ran = true;
         }
-        // (as in traverse_pairs_vote: a leaf or shading step is followed by a node step without a vote in between)
-        if (2 * n_node < n_active)                 // (the other two counts exist on this path only: the short path goes straight to the node step)
-        if (!(n_node >= n_leaf && n_node >= n_done)) {
-            if (n_leaf >= n_done) {
-                if ((int32_t) ref < (int32_t) IDLE) {
-                    const uint32_t first = ref & 0x0FFFFFFFu;
-                    const uint32_t count = ((ref >> 28) & 7u) + 1u;
-                    float dist = 0.0f;
-                    uint32_t idx = NONE;
-                    if (c < count) {
-                        const float4 * tp = reinterpret_cast<const float4 *>(tri_base + tri_byte_offset(first + c));
-                        float4 ta = tp[0], tb = tp[1], tc = tp[2];
-                        asm volatile("" : "+v"(ta.x), "+v"(tb.x), "+v"(tc.x));     // all three loads leave before the first use
-                        dist = mt_intersect(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), o, d);
-                        idx = __float_as_uint(tc.y);
-                    }
-                    // kernel.cpp:180-188 — smallest distance wins, equal distances go to the lower index.  A candidate
-                    // distance is > EPSILON > 0, and positive floats order like their bit patterns, so (distance, index)
-                    // is ONE unsigned 64-bit key: the quad minimum and the comparison with the best so far are three
-                    // 64-bit compares.  "No hit" is (+inf, NONE), the largest key a lane can hold.
-                    const bool valid = c < count && dist > RVB_EPSILON;
-                    unsigned long long key = valid ? (((unsigned long long) __float_as_uint(dist) << 32) | idx) : NO_HIT_KEY;
-                    key = min_u64(key, dpp_u64<QP_SWAP1>(key));
-                    key = min_u64(key, dpp_u64<QP_SWAP2>(key));
-                    best_key = min_u64(best_key, key);
-                    if (sp > 0) { --sp; ref = stack[sp * QUADS_PER_BLOCK]; } else ref = NONE;
-                }
-            } else {
-                if (ref == NONE) {
-                    Hit h;
-                    h.t = __uint_as_float((uint32_t) (best_key >> 32));
-                    h.tri = (uint32_t) best_key;
-                    job.done(h.tri != NONE, h);
-                    ref = IDLE;
-                    if (job.next(o, d, tmax)) RVB_RESET_QUERY()
-                }
-                n_active = scalar_popcount(__builtin_amdgcn_ballot_w64(ref != IDLE));
-            }
-        }
-        {
-            if ((int32_t) ref >= 0) {
-#if RVB_LDS_NODES
-                uint4 n;
-                if (ref < RVB_LDS_NODES * 64u) { const nt_float4 t = lds_nodes[(ref | child_off) >> 4]; n = make_uint4(__float_as_uint(t.x), __float_as_uint(t.y), __float_as_uint(t.z), __float_as_uint(t.w)); }
-                else n = *reinterpret_cast<const uint4 *>(node_base + (ref | child_off));
-#else
-                const uint4 n = *reinterpret_cast<const uint4 *>(node_base + (ref | child_off));
-#endif
-                const float limit = fmaf(__uint_as_float((uint32_t) (best_key >> 32)), cull_scale, sc.cull_abs);
-                float tn;
-                const bool ok = RVB_QUAD_SLAB(n, tn);
-                const uint32_t cref = n.w;
-                const uint32_t key = ok ? ((__float_as_uint(fmaxf(tn, 0.0f)) & ~3u) | c) : NONE;
-                uint32_t kmin = min(key, dpp_u<QP_SWAP1>(key));
-                kmin = min(kmin, dpp_u<QP_SWAP2>(kmin));
-                if (kmin == NONE) {
-                    if (sp > 0) { --sp; ref = stack[sp * QUADS_PER_BLOCK]; } else ref = NONE;
-                } else {
-                    const uint32_t winner = kmin & 3u;
-                    uint32_t okmask = ok ? lane_bit : 0u;
-                    okmask |= dpp_u<QP_SWAP1>(okmask);
-                    okmask |= dpp_u<QP_SWAP2>(okmask);
-                    const uint32_t rest = okmask & ~(1u << winner);
-                    if (ok && c != winner)
-                        stack[(sp + __popc(rest & lt_mask)) * QUADS_PER_BLOCK] = cref;
-                    sp += __popc(rest);
-                    ref = (uint32_t) __builtin_amdgcn_ds_bpermute((int) (lane_base4 + (winner << 2)), (int) cref);
-                }
-            }
-        }
+        const int n_done = scalar_popcount(__builtin_amdgcn_ballot_w64(ref == NONE));
+        if (n_done && (RVB_CYCLE_DONE_NUM * n_done >= RVB_CYCLE_DONE_DEN * n_active || !ran))
+            shading_step();
     }
 #undef RVB_RESET_QUERY
 }
@@ -606,156 +613,167 @@ __device__ __forceinline__ void traverse_pairs_vote(const SceneDev & sc, uint32_
 #endif
     if (job.next(o, d, tmax)) RVB_RESET_QUERY()
     // lanes that carry a ray (not IDLE): changes in shading steps only
-    int n_active = scalar_popcount(__builtin_amdgcn_ballot_w64(ref != IDLE));
+    int n_active = 0;                    // lanes that carry a ray (not IDLE): changes in shading steps only
+    // the three step kinds of the loop (inlined where the schedule below calls them)
+    auto leaf_step = [&]() {
+        RVB_MARK("leaf");
+#if RVB_STAMPS == 1
+        if ((int32_t) ref < (int32_t) IDLE) {
+            const uint32_t first = ref & 0x0FFFFFFFu, count = ((ref >> 28) & 7u) + 1u;
+            const float4 * q0 = reinterpret_cast<const float4 *>(tri_base + tri_byte_offset(first + (h < count ? h : 0u)));
+            const float4 * q1 = reinterpret_cast<const float4 *>(tri_base + tri_byte_offset(first + (h + 2u < count ? h + 2u : 0u)));
+            float4 w0 = q0[0], w1 = q0[2], w2 = q1[0], w3 = q1[2];
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0.x), "+v"(w1.x), "+v"(w2.x), "+v"(w3.x) :: "memory");
+        }
+        STAMP(t_b)
+        sv[3] += t_b - t_a; sn[1] += 1;
+#endif
+        if ((int32_t) ref < (int32_t) IDLE) {
+            // triangles h and h + 2 of the leaf (a two-triangle leaf gives each lane one)
+            const uint32_t first = ref & 0x0FFFFFFFu;
+            const uint32_t count = ((ref >> 28) & 7u) + 1u;
+            const uint32_t j0 = h, j1 = h + 2u;
+            const float4 * tp0 = reinterpret_cast<const float4 *>(tri_base + tri_byte_offset(first + (j0 < count ? j0 : 0u)));
+            const float4 * tp1 = reinterpret_cast<const float4 *>(tri_base + tri_byte_offset(first + (j1 < count ? j1 : 0u)));
+            float4 ta = tp0[0], tb = tp0[1], tc = tp0[2], ua = tp1[0], ub = tp1[1], uc = tp1[2];
+            asm volatile("" : "+v"(ta.x), "+v"(tb.x), "+v"(tc.x), "+v"(ua.x), "+v"(ub.x), "+v"(uc.x));   // all six loads leave before the first use
+            const float dist0 = mt_intersect(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), o, d);
+            const float dist1 = mt_intersect(mk3(ua.x, ua.y, ua.z), mk3(ua.w, ub.x, ub.y), mk3(ub.z, ub.w, uc.x), o, d);
+            // kernel.cpp:180-188 — smallest distance wins, equal distances go to the lower index: one unsigned 64-bit key
+            const bool valid0 = j0 < count && dist0 > RVB_EPSILON, valid1 = j1 < count && dist1 > RVB_EPSILON;
+            const unsigned long long k0 = valid0 ? (((unsigned long long) __float_as_uint(dist0) << 32) | __float_as_uint(tc.y)) : NO_HIT_KEY;
+            const unsigned long long k1 = valid1 ? (((unsigned long long) __float_as_uint(dist1) << 32) | __float_as_uint(uc.y)) : NO_HIT_KEY;
+            unsigned long long key = min_u64(k0, k1);
+            key = min_u64(key, dpp_u64<QP_SWAP1>(key));
+            best_key = min_u64(best_key, key);
+            RVB_PAIR_LIMIT();
+            RVB_PAIR_POP()
+        }
+#if RVB_STAMPS == 1
+        STAMP(t_c)
+        sv[4] += t_c - t_b;
+#endif
+    };
+    auto shading_step = [&]() {
+        RVB_MARK("done");
+        if (ref == NONE) {
+            Hit hit;
+            hit.t = __uint_as_float((uint32_t) (best_key >> 32));
+            hit.tri = (uint32_t) best_key;
+            job.done(hit.tri != NONE, hit);
+            ref = IDLE;
+            if (job.next(o, d, tmax)) RVB_RESET_QUERY()
+        }
+        n_active = scalar_popcount(__builtin_amdgcn_ballot_w64(ref != IDLE));
+#if RVB_STAMPS == 1
+        STAMP(t_c)
+        sv[5] += t_c - t_a; sn[2] += 1;
+        t_a = t_c;
+#endif
+    };
+    auto node_step = [&]() {
+        RVB_MARK("node");
+#if RVB_STAMPS == 1
+        if ((int32_t) ref >= 0) {
+            const uint4 * pp = reinterpret_cast<const uint4 *>(node_base + (ref | child_off));
+            uint4 w0 = pp[0], w1 = pp[1];
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0.x), "+v"(w1.x) :: "memory");     // the step's own loads hit the L1 afterwards
+        }
+        STAMP(t_b)
+        sv[1] += t_b - t_a; sn[0] += 1;
+#endif
+        if ((int32_t) ref >= 0) {
+#if RVB_LDS_NODES
+            uint4 n0, n1;
+            if (ref < RVB_LDS_NODES * 64u) {
+                const nt_float4 t0 = lds_nodes[(ref | child_off) >> 4], t1 = lds_nodes[((ref | child_off) >> 4) + 1];
+                n0 = make_uint4(__float_as_uint(t0.x), __float_as_uint(t0.y), __float_as_uint(t0.z), __float_as_uint(t0.w));
+                n1 = make_uint4(__float_as_uint(t1.x), __float_as_uint(t1.y), __float_as_uint(t1.z), __float_as_uint(t1.w));
+            } else {
+                const uint4 * np = reinterpret_cast<const uint4 *>(node_base + (ref | child_off));
+                n0 = np[0]; n1 = np[1];
+            }
+#else
+            const uint4 * np = reinterpret_cast<const uint4 *>(node_base + (ref | child_off));
+            const uint4 n0 = np[0], n1 = np[1];
+#endif
+            float tn0, tn1;
+            const bool ok0 = RVB_PAIR_SLAB(RVB_PAIR_SELECT & 1, n0, tn0, job.skip_ref());
+            const bool ok1 = RVB_PAIR_SLAB(RVB_PAIR_SELECT & 1, n1, tn1, job.skip_ref());
+            // the hit children's keys: entry distance (its two low bits give way to the child number), compared as SIGNED integers —
+            // negative distances (the origin is inside the box, or the box a rounding behind it) come before all others, in any
+            // order; tools/travforms.cpp replays the same number of node visits as with keys of max(distance, 0)
+            const uint32_t NO_CHILD = 0x7FFFFFFFu;
+            // ((distance & ~3) | child) as one v_bitop3_b32 with register operands: issues at the rate of v_fma_f32, the and_or
+            // form at 0.6 of it (profiles/r04b_inst_probe.log)
+            const uint32_t key0 = ok0 ? __builtin_amdgcn_bitop3_b32(__float_as_uint(tn0), clear2, c0, 0xEA) : NO_CHILD;
+            const uint32_t key1 = ok1 ? __builtin_amdgcn_bitop3_b32(__float_as_uint(tn1), clear2, c1, 0xEA) : NO_CHILD;
+            uint32_t kmin = (uint32_t) min((int32_t) key0, (int32_t) key1);
+            kmin = (uint32_t) min((int32_t) kmin, (int32_t) dpp_u<QP_SWAP1>(kmin));
+            if (kmin == NO_CHILD) {
+                RVB_PAIR_POP()
+            } else {
+                // the pair's pushes in child order (as below) from the lanes' COUNTS: a lane's kept children go on top of the other
+                // lane's if it is the pair's second lane, so one 2-bit count crosses the pair instead of the hit mask, and a lane's
+                // rows follow from its own two flags (the keys name the child: key == kmin is the winner)
+                const bool other0 = key0 != kmin, other1 = key1 != kmin;
+                const bool keep0 = ok0 && other0, keep1 = ok1 && other1;
+                const uint32_t first = keep0 ? PAIR_ROW : 0u;                          // counts in bytes of stack rows
+                const uint32_t n_mine = first + (keep1 ? PAIR_ROW : 0u);
+                const uint32_t n_theirs = dpp_u<QP_SWAP1>(n_mine);
+                const uint32_t row = __umul24(n_theirs, h) + sp;                       // sp + (h ? n_theirs : 0) as one v_mad_u32_u24
+                if (keep0)
+                    *(lds_u32_ptr) (uintptr_t) row = n0.w;
+                if (keep1)
+                    *(lds_u32_ptr) (uintptr_t) (row + first) = n1.w;
+                // the winner is the child whose key IS kmin (keys carry the child number)
+                const uint32_t mine = other1 ? (other0 ? 0u : n0.w) : n1.w;            // 0 in the lane that does not own it
+                sp += n_mine + n_theirs;
+                ref = mine | dpp_u<QP_SWAP1>(mine);
+            }
+        }
+#if RVB_STAMPS == 1
+        STAMP(t_c)
+        sv[2] += t_c - t_b;
+#endif
+    };
+    // THE SCHEDULE (round 4).  Rounds 1-3 voted: every iteration three ballots, and the step kind most lanes waited for was executed.  A wave's time,
+    // though, goes into the LATENCY of its own instruction stream (tools/pair_stamps.py: 300 of an iteration's 1 900 cycles were the vote's dependent
+    // scalar chain), so the vote was first shortened (one ballot while the lanes at a node are a majority: two-lane kernel alone 3.54 -> 3.46 ms,
+    // four-lane kernel 3.54 -> 3.31), then a node step was chained behind every leaf and shading step (same steps, 28.7 votes instead of 36.2 per
+    // 32 ray-bounces: 3.43 -> 3.27 / 3.32 -> 3.22 ms) — and then dropped: every iteration is a node step for the lanes at a node, then a leaf step if a
+    // third of the live lanes wait for one, then a shading step if a quarter of them do (or if nothing else could run).  tools/travforms.cpp
+    // (TRAVFORMS_CYCLE) replays 23.7 node + 6.3 leaf + 3.2 shading steps per 32 ray-bounces at C2 where the majority vote takes 28.6 + 5.2 + 2.6 (C4:
+    // 26.5 + 5.9 + 3.3 against 32.0 + 4.9 + 2.6): lanes waiting at a leaf need not become the largest group before they are served, and the node steps
+    // run fuller (0.61 of the lanes instead of 0.52).  Two-lane kernel alone 3.27 -> 3.16 ms (100 k rays), 1.86 -> 1.80 ms per 100 k rays at 800 k;
+    // four-lane kernel 3.27 -> 3.13 ms; pipeline 4.22 -> 4.12 ms per IR (profiles/r04d_cycle*_n1.txt; thresholds of 25-40 % all within 1 %).
+    // Same queries, same results: the schedule only decides WHEN a lane's next step runs.  What did not help a wave's latency: one dword of the next
+    // node requested a step ahead (a third L1 access per step costs more than its head start: 3.40 -> 3.81 ms), two node steps per iteration.
+    n_active = scalar_popcount(__builtin_amdgcn_ballot_w64(ref != IDLE));
     for (;;) {
         RVB_MARK("vote");
-        // The vote, short form: a wave's time goes into the LATENCY of its instructions (a dependent scalar chain behind three ballots is
-        // 300 of an iteration's 1 900 cycles, tools/pair_stamps.py), and four iterations in five are node steps.  When the lanes at a node
-        // are half of the live lanes or more they are the largest group whatever the other two counts are: those are then not formed.
-        // Alone on the GPU 3.54 -> 3.46 ms (100 k rays), 1.98 -> 1.94 ms per 100 k rays at 800 k; pipeline 4.30 -> 4.24 ms per IR
-        // (profiles/r04c_short_vote_n1.txt).  What does NOT help a wave's latency: requesting one dword of the next node before the
-        // vote so that the step's loads find the line in the L1 — 3.40 -> 3.81 ms alone, 4.23 -> 4.49 in the pipeline, and worse
-        // with the leaf's first triangle too (profiles/r04c_prefetch_n1.txt): a third access per step costs the L1 more than the
-        // 300 cycles of head start are worth, as with the one-lane kernel's four.
         if (n_active == 0)
             break;
-        const int n_node = scalar_popcount(__builtin_amdgcn_ballot_w64((int32_t) ref >= 0));
-        int n_done = 0, n_leaf = 0;
-        if (2 * n_node < n_active) {
-            n_done = scalar_popcount(__builtin_amdgcn_ballot_w64(ref == NONE));
-            n_leaf = scalar_popcount(__builtin_amdgcn_ballot_w64((int32_t) ref < (int32_t) IDLE));
-        }
+        bool ran = __builtin_amdgcn_ballot_w64((int32_t) ref >= 0) != 0ull;
 #if RVB_STAMPS == 1
         STAMP(t_a)
         sv[0] += t_a - t_c;
 #endif
-        // A leaf or shading step is FOLLOWED by a node step, without a vote in between: the lanes it served are at a node afterwards (a popped
-        // entry, the root of the next bounce) together with those that were waiting for one.  tools/travforms.cpp (TRAVFORMS_CHAIN) replays the
-        // same number of wave steps of every kind — 28.6 node, 5.2 leaf, 2.6 shading per 32 ray-bounces — with 28.7 votes instead of 36.2.
-        if (2 * n_node < n_active)                 // (the other two counts exist on this path only: the short path goes straight to the node step)
-        if (!(n_node >= n_leaf && n_node >= n_done)) {
-            if (n_leaf >= n_done) {
-                RVB_MARK("leaf");
+        node_step();
 #if RVB_STAMPS == 1
-                if ((int32_t) ref < (int32_t) IDLE) {
-                    const uint32_t first = ref & 0x0FFFFFFFu, count = ((ref >> 28) & 7u) + 1u;
-                    const float4 * q0 = reinterpret_cast<const float4 *>(tri_base + tri_byte_offset(first + (h < count ? h : 0u)));
-                    const float4 * q1 = reinterpret_cast<const float4 *>(tri_base + tri_byte_offset(first + (h + 2u < count ? h + 2u : 0u)));
-                    float4 w0 = q0[0], w1 = q0[2], w2 = q1[0], w3 = q1[2];
-                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0.x), "+v"(w1.x), "+v"(w2.x), "+v"(w3.x) :: "memory");
-                }
-                STAMP(t_b)
-                sv[3] += t_b - t_a; sn[1] += 1;
+        t_a = t_c;
 #endif
-                if ((int32_t) ref < (int32_t) IDLE) {
-                    // triangles h and h + 2 of the leaf (a two-triangle leaf gives each lane one)
-                    const uint32_t first = ref & 0x0FFFFFFFu;
-                    const uint32_t count = ((ref >> 28) & 7u) + 1u;
-                    const uint32_t j0 = h, j1 = h + 2u;
-                    const float4 * tp0 = reinterpret_cast<const float4 *>(tri_base + tri_byte_offset(first + (j0 < count ? j0 : 0u)));
-                    const float4 * tp1 = reinterpret_cast<const float4 *>(tri_base + tri_byte_offset(first + (j1 < count ? j1 : 0u)));
-                    float4 ta = tp0[0], tb = tp0[1], tc = tp0[2], ua = tp1[0], ub = tp1[1], uc = tp1[2];
-                    asm volatile("" : "+v"(ta.x), "+v"(tb.x), "+v"(tc.x), "+v"(ua.x), "+v"(ub.x), "+v"(uc.x));   // all six loads leave before the first use
-                    const float dist0 = mt_intersect(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), o, d);
-                    const float dist1 = mt_intersect(mk3(ua.x, ua.y, ua.z), mk3(ua.w, ub.x, ub.y), mk3(ub.z, ub.w, uc.x), o, d);
-                    // kernel.cpp:180-188 — smallest distance wins, equal distances go to the lower index: one unsigned 64-bit key
-                    const bool valid0 = j0 < count && dist0 > RVB_EPSILON, valid1 = j1 < count && dist1 > RVB_EPSILON;
-                    const unsigned long long k0 = valid0 ? (((unsigned long long) __float_as_uint(dist0) << 32) | __float_as_uint(tc.y)) : NO_HIT_KEY;
-                    const unsigned long long k1 = valid1 ? (((unsigned long long) __float_as_uint(dist1) << 32) | __float_as_uint(uc.y)) : NO_HIT_KEY;
-                    unsigned long long key = min_u64(k0, k1);
-                    key = min_u64(key, dpp_u64<QP_SWAP1>(key));
-                    best_key = min_u64(best_key, key);
-                    RVB_PAIR_LIMIT();
-                    RVB_PAIR_POP()
-                }
+        const int n_leaf = scalar_popcount(__builtin_amdgcn_ballot_w64((int32_t) ref < (int32_t) IDLE));
+        if (n_leaf && (RVB_CYCLE_LEAF_NUM * n_leaf >= RVB_CYCLE_LEAF_DEN * n_active || !ran)) {
+            leaf_step();
+            ran = true;
 #if RVB_STAMPS == 1
-                STAMP(t_c)
-                sv[4] += t_c - t_b;
-#endif
-            } else {
-                RVB_MARK("done");
-                if (ref == NONE) {
-                    Hit hit;
-                    hit.t = __uint_as_float((uint32_t) (best_key >> 32));
-                    hit.tri = (uint32_t) best_key;
-                    job.done(hit.tri != NONE, hit);
-                    ref = IDLE;
-                    if (job.next(o, d, tmax)) RVB_RESET_QUERY()
-                }
-                n_active = scalar_popcount(__builtin_amdgcn_ballot_w64(ref != IDLE));
-#if RVB_STAMPS == 1
-                STAMP(t_c)
-                sv[5] += t_c - t_a; sn[2] += 1;
-                t_a = t_c;
-#endif
-            }
-        }
-        {
-            RVB_MARK("node");
-#if RVB_STAMPS == 1
-            if ((int32_t) ref >= 0) {
-                const uint4 * pp = reinterpret_cast<const uint4 *>(node_base + (ref | child_off));
-                uint4 w0 = pp[0], w1 = pp[1];
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0.x), "+v"(w1.x) :: "memory");     // the step's own loads hit the L1 afterwards
-            }
-            STAMP(t_b)
-            sv[1] += t_b - t_a; sn[0] += 1;
-#endif
-            if ((int32_t) ref >= 0) {
-#if RVB_LDS_NODES
-                uint4 n0, n1;
-                if (ref < RVB_LDS_NODES * 64u) {
-                    const nt_float4 t0 = lds_nodes[(ref | child_off) >> 4], t1 = lds_nodes[((ref | child_off) >> 4) + 1];
-                    n0 = make_uint4(__float_as_uint(t0.x), __float_as_uint(t0.y), __float_as_uint(t0.z), __float_as_uint(t0.w));
-                    n1 = make_uint4(__float_as_uint(t1.x), __float_as_uint(t1.y), __float_as_uint(t1.z), __float_as_uint(t1.w));
-                } else {
-                    const uint4 * np = reinterpret_cast<const uint4 *>(node_base + (ref | child_off));
-                    n0 = np[0]; n1 = np[1];
-                }
-#else
-                const uint4 * np = reinterpret_cast<const uint4 *>(node_base + (ref | child_off));
-                const uint4 n0 = np[0], n1 = np[1];
-#endif
-                float tn0, tn1;
-                const bool ok0 = RVB_PAIR_SLAB(RVB_PAIR_SELECT & 1, n0, tn0, job.skip_ref());
-                const bool ok1 = RVB_PAIR_SLAB(RVB_PAIR_SELECT & 1, n1, tn1, job.skip_ref());
-                // the hit children's keys: entry distance (its two low bits give way to the child number), compared as SIGNED integers —
-                // negative distances (the origin is inside the box, or the box a rounding behind it) come before all others, in any
-                // order; tools/travforms.cpp replays the same number of node visits as with keys of max(distance, 0)
-                const uint32_t NO_CHILD = 0x7FFFFFFFu;
-                // ((distance & ~3) | child) as one v_bitop3_b32 with register operands: issues at the rate of v_fma_f32, the and_or
-                // form at 0.6 of it (profiles/r04b_inst_probe.log)
-                const uint32_t key0 = ok0 ? __builtin_amdgcn_bitop3_b32(__float_as_uint(tn0), clear2, c0, 0xEA) : NO_CHILD;
-                const uint32_t key1 = ok1 ? __builtin_amdgcn_bitop3_b32(__float_as_uint(tn1), clear2, c1, 0xEA) : NO_CHILD;
-                uint32_t kmin = (uint32_t) min((int32_t) key0, (int32_t) key1);
-                kmin = (uint32_t) min((int32_t) kmin, (int32_t) dpp_u<QP_SWAP1>(kmin));
-                if (kmin == NO_CHILD) {
-                    RVB_PAIR_POP()
-                } else {
-                    // the pair's pushes in child order (as below) from the lanes' COUNTS: a lane's kept children go on top of the other
-                    // lane's if it is the pair's second lane, so one 2-bit count crosses the pair instead of the hit mask, and a lane's
-                    // rows follow from its own two flags (the keys name the child: key == kmin is the winner)
-                    const bool other0 = key0 != kmin, other1 = key1 != kmin;
-                    const bool keep0 = ok0 && other0, keep1 = ok1 && other1;
-                    const uint32_t first = keep0 ? PAIR_ROW : 0u;                          // counts in bytes of stack rows
-                    const uint32_t n_mine = first + (keep1 ? PAIR_ROW : 0u);
-                    const uint32_t n_theirs = dpp_u<QP_SWAP1>(n_mine);
-                    const uint32_t row = __umul24(n_theirs, h) + sp;                       // sp + (h ? n_theirs : 0) as one v_mad_u32_u24
-                    if (keep0)
-                        *(lds_u32_ptr) (uintptr_t) row = n0.w;
-                    if (keep1)
-                        *(lds_u32_ptr) (uintptr_t) (row + first) = n1.w;
-                    // the winner is the child whose key IS kmin (keys carry the child number)
-                    const uint32_t mine = other1 ? (other0 ? 0u : n0.w) : n1.w;            // 0 in the lane that does not own it
-                    sp += n_mine + n_theirs;
-                    ref = mine | dpp_u<QP_SWAP1>(mine);
-                }
-            }
-#if RVB_STAMPS == 1
-            STAMP(t_c)
-            sv[2] += t_c - t_b;
+            t_a = t_c;
 #endif
         }
+        const int n_done = scalar_popcount(__builtin_amdgcn_ballot_w64(ref == NONE));
+        if (n_done && (RVB_CYCLE_DONE_NUM * n_done >= RVB_CYCLE_DONE_DEN * n_active || !ran))
+            shading_step();
         RVB_MARK("loop_end");
     }
 #if RVB_STAMPS

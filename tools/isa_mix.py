@@ -67,7 +67,7 @@ def issue_cost(line):
 
 
 def main():
-    steps = [float(x) for x in sys.argv[1:4]] if len(sys.argv) >= 4 else [28.66, 5.14, 2.57]      # travsim, C2, 32 rays per wave
+    steps = [float(x) for x in sys.argv[1:4]] if len(sys.argv) >= 4 else [23.73, 6.30, 3.18]      # travforms (TRAVFORMS_CYCLE=34,25), C2, 32 rays per wave; the majority vote of rounds 1-3: 28.66 5.14 2.57
     asm = "/tmp/isa_mix.s"
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
                            "-fhip-fp32-correctly-rounded-divide-sqrt", "-munsafe-fp-atomics", "-fno-slp-vectorize", "--cuda-device-only",
@@ -91,7 +91,7 @@ def main():
             continue
         blocks[current][classify(op)] += 1
         cost[current] += issue_cost(line)
-    weights = {"vote": steps[0] + steps[1] + steps[2], "node": steps[0], "leaf": steps[1], "done": steps[2]}
+    weights = {"vote": steps[0], "node": steps[0], "leaf": steps[1], "done": steps[2]}      # one loop iteration per node step
     print("static instruction counts per block of traverse_pairs_vote (path_pair_kernel<true>), and per bounce of one wave (32 rays)")
     print("weights = wave-level executions per bounce: %s" % weights)
     total = collections.Counter()

@@ -216,26 +216,7 @@ static void run_wave(Sim & s, std::vector<RayState *> & rays, uint32_t stop_boun
     for (int i = 0; i < nq; ++i)
         if (rays[i]->alive && rays[i]->bounce < stop_bounce) { s.begin(q[i], rays[i]->o, rays[i]->d, rays[i]->skip); st[i] = NODE; }
     auto classify = [&](int i) { st[i] = q[i].ref == 0xFFFFFFFFu ? DONE : ((q[i].ref & RVB_BVH_LEAF) ? LEAF : NODE); };
-    for (;;) {
-        int c[3] = {0, 0, 0};
-        for (int i = 0; i < nq; ++i) if (st[i] != IDLE) ++c[st[i]];
-        if (c[0] + c[1] + c[2] == 0) break;
-        int a = NODE;                                            // n_node >= n_leaf && n_node >= n_done, else leaf >= done, else done
-        if (!(c[0] >= c[1] && c[0] >= c[2])) a = c[1] >= c[2] ? LEAF : DONE;
-        ++cnt[a]; act[a] += c[a];
-        ++g_votes;
-        const bool strong = a == NODE && g_double > 0 && c[0] * 100 >= g_double * (c[0] + c[1] + c[2]);
-        for (int pass = 0; pass < 2; ++pass) {
-        if (pass == 1) {
-            // TRAVFORMS_CHAIN=1: a leaf or shading step is followed by a node step for the lanes that are at a node by then, without a vote;
-            // TRAVFORMS_DOUBLE=P: a node step voted for by P % of the live lanes or more is followed by a second one without a vote
-            if (!((g_chain && a != NODE) || strong)) break;
-            a = NODE;
-            int at_node = 0;
-            for (int i = 0; i < nq; ++i) at_node += st[i] == NODE;
-            if (!at_node) break;
-            ++cnt[a]; act[a] += at_node;
-        }
+    auto do_step = [&](int a) {
         for (int i = 0; i < nq; ++i) {
             if (st[i] != (St) a) continue;
             if (a == NODE) { s.node_step(q[i]); classify(i); }
@@ -267,6 +248,39 @@ static void run_wave(Sim & s, std::vector<RayState *> & rays, uint32_t stop_boun
                 st[i] = NODE;
             }
         }
+    };
+    const char * cyc = getenv("TRAVFORMS_CYCLE");        // "TL,TD": no vote — every iteration a node step, then a leaf step if TL % of the live lanes
+    int TL = 0, TD = 0;                                   // wait for one, then a shading step if TD % do (or if nothing else can run)
+    if (cyc) sscanf(cyc, "%d,%d", &TL, &TD);
+    for (;;) {
+        int c[3] = {0, 0, 0};
+        for (int i = 0; i < nq; ++i) if (st[i] != IDLE) ++c[st[i]];
+        if (c[0] + c[1] + c[2] == 0) break;
+        if (cyc) {
+            ++g_votes;
+            const int live = c[0] + c[1] + c[2];
+            bool ran = false;
+            if (c[0]) { ++cnt[NODE]; act[NODE] += c[0]; do_step(NODE); ran = true; }
+            int l = 0, dn = 0;
+            for (int i = 0; i < nq; ++i) { l += st[i] == LEAF; dn += st[i] == DONE; }
+            if (l && (l * 100 >= TL * live || !ran)) { ++cnt[LEAF]; act[LEAF] += l; do_step(LEAF); ran = true; }
+            dn = 0;
+            for (int i = 0; i < nq; ++i) dn += st[i] == DONE;
+            if (dn && (dn * 100 >= TD * live || !ran)) { ++cnt[DONE]; act[DONE] += dn; do_step(DONE); }
+            continue;
+        }
+        int a = NODE;                                            // n_node >= n_leaf && n_node >= n_done, else leaf >= done, else done
+        if (!(c[0] >= c[1] && c[0] >= c[2])) a = c[1] >= c[2] ? LEAF : DONE;
+        ++cnt[a]; act[a] += c[a];
+        ++g_votes;
+        const bool strong = a == NODE && g_double > 0 && c[0] * 100 >= g_double * (c[0] + c[1] + c[2]);
+        do_step(a);
+        if ((g_chain && a != NODE) || strong) {
+            // TRAVFORMS_CHAIN=1: a leaf or shading step is followed by a node step for the lanes that are at a node by then, without a vote;
+            // TRAVFORMS_DOUBLE=P: a node step voted for by P % of the live lanes or more is followed by a second one without a vote
+            int at_node = 0;
+            for (int i = 0; i < nq; ++i) at_node += st[i] == NODE;
+            if (at_node) { ++cnt[NODE]; act[NODE] += at_node; do_step(NODE); }
         }
     }
 }
