@@ -260,7 +260,12 @@ static void run_wave(Sim & s, std::vector<RayState *> & rays, uint32_t stop_boun
             ++g_votes;
             const int live = c[0] + c[1] + c[2];
             bool ran = false;
-            if (c[0]) { ++cnt[NODE]; act[NODE] += c[0]; do_step(NODE); ran = true; }
+            static const int node_reps = getenv("TRAVFORMS_CYCLE_NODES") ? atoi(getenv("TRAVFORMS_CYCLE_NODES")) : 1;
+            for (int rep = 0; rep < node_reps; ++rep) {
+                int at = 0;
+                for (int i = 0; i < nq; ++i) at += st[i] == NODE;
+                if (at) { ++cnt[NODE]; act[NODE] += at; do_step(NODE); ran = true; }
+            }
             int l = 0, dn = 0;
             for (int i = 0; i < nq; ++i) { l += st[i] == LEAF; dn += st[i] == DONE; }
             if (l && (l * 100 >= TL * live || !ran)) { ++cnt[LEAF]; act[LEAF] += l; do_step(LEAF); ran = true; }
