@@ -261,10 +261,12 @@ static void run_wave(Sim & s, std::vector<RayState *> & rays, uint32_t stop_boun
             const int live = c[0] + c[1] + c[2];
             bool ran = false;
             static const int node_reps = getenv("TRAVFORMS_CYCLE_NODES") ? atoi(getenv("TRAVFORMS_CYCLE_NODES")) : 1;
+            static const int TN = getenv("TRAVFORMS_CYCLE_TN") ? atoi(getenv("TRAVFORMS_CYCLE_TN")) : 0;     // node step only if TN % of the live lanes are at a node (or nothing else would run)
             for (int rep = 0; rep < node_reps; ++rep) {
-                int at = 0;
-                for (int i = 0; i < nq; ++i) at += st[i] == NODE;
-                if (at) { ++cnt[NODE]; act[NODE] += at; do_step(NODE); ran = true; }
+                int at = 0, lf = 0, dd = 0;
+                for (int i = 0; i < nq; ++i) { at += st[i] == NODE; lf += st[i] == LEAF; dd += st[i] == DONE; }
+                const bool others = (lf && lf * 100 >= TL * live) || (dd && dd * 100 >= TD * live);
+                if (at && (at * 100 >= TN * live || !others)) { ++cnt[NODE]; act[NODE] += at; do_step(NODE); ran = true; }
             }
             int l = 0, dn = 0;
             for (int i = 0; i < nq; ++i) { l += st[i] == LEAF; dn += st[i] == DONE; }
