@@ -41,6 +41,7 @@ from parallel_reverb_raytracer_amd import capi, distributed, dtypes, scenes  # n
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 # the guide's vector issue rate: v_fma_f32 (wave64) 2 cycles on each of 256 x 4 SIMDs at 2.4 GHz
 VALU_FMA_PEAK_GINST = 256 * 4 * 2.4 / 2
+HELD_CLOCK_GHZ = 2.32      # measured in the pipeline of this bench (profiles/r04c_pair_stamps_n1.txt), against the 2.4 GHz the issue model assumes
 PMC_FILE = "r04c_pmc_n1.json"      # committed PMC passes of this command (tools/profile.sh): instruction mix, lane utilisation, HBM bytes
 BYTES_PER_BOUNCE = 69.75          # 64 B Impulse per bounce + (16 B direction + 10 x 72 B image slots) per ray at 128 bounces
 
@@ -544,7 +545,10 @@ def main():
                 per_ir += parts[k]
             valu["whole_step"] = {"bound": "valu_issue", "issue_model_ms_per_ir": per_ir, "ms_per_ir_timed_region": ms_per_step,
                                   "frac": per_ir / ms_per_step, "issue_model_ms_by_kernel": parts, "numerators": from_profile,
-                                  "note": "sum over the kernels of one IR of (VALU issue-model time per launch x launches per IR) / measured time per IR"}
+                                  "note": "sum over the kernels of one IR of (VALU issue-model time per launch x launches per IR) / measured time per IR",
+                                  # the issue costs are cycles at 2.4 GHz; the chip holds 2.32 GHz while this pipeline runs (shader cycles over 100-MHz
+                                  # ticks around the path kernel's loop: tools/pair_stamps.py pipeline, profiles/r04c_pair_stamps_n1.txt)
+                                  "held_clock_ghz": HELD_CLOCK_GHZ, "frac_at_held_clock": per_ir / ms_per_step * 2.4 / HELD_CLOCK_GHZ}
         stream = {}
         algorithmic = {"shadow_kernel": 128.0 * nrays * nrefl,          # 64-byte work record read, 64-byte Impulse written
                        "shadow_pair_kernel": 128.0 * nrays * nrefl,
