@@ -365,6 +365,7 @@ int main(int argc, char ** argv)
     forms.push_back({"pairs, stack per lane, lane 0's first", 32, 4, true, 0, 67, 146, 75, 1});
     forms.push_back({"pairs, stack per lane, larger first", 32, 4, true, 0, 67, 146, 75, 2});
     forms.push_back({"pairs, stack per lane, last pushed first", 32, 4, true, 0, 67, 146, 75, 3});
+    forms.push_back({"quads (four lanes per ray, 16 rays per wave)", 16, 4, true, 0, 51, 89, 85});
     forms.push_back({"pairs, pushes from counts (round 4: 61 / 143 / 98 + 4 copies per step)", 32, 4, true, 0, 65, 147, 102, 0, 0});
     forms.push_back({"pairs, pushes from counts, signed keys of the unclamped entry distance", 32, 4, true, 0, 63, 147, 102, 0, 1});
     for (int K : {1, 2, 4, 8, 16, 32}) {
