@@ -72,7 +72,7 @@ def pairs_pipelined(scene, src, mic, nrays, nrefl, npairs):
     ctxs = []
     for _ in range(2):
         c = capi.Context(0)
-        if ctxs:
+        if ctxs and not os.environ.get("CONFIG_BENCH_OWN_SCENES"):
             c.share_scene(ctxs[0])              # one copy of the scene for the contexts of the GPU
         else:
             c.set_scene(scene)
@@ -132,7 +132,7 @@ def native_pipeline(name, scene, jobs, nrays, nrefl, hrtf, contexts=4, repeats=3
     ctxs = []
     for _ in range(contexts):
         c = capi.Context(0)
-        if ctxs:
+        if ctxs and not os.environ.get("CONFIG_BENCH_OWN_SCENES"):
             c.share_scene(ctxs[0])              # one copy of the scene for the contexts of the GPU
         else:
             c.set_scene(scene)
@@ -175,6 +175,13 @@ def native_pipeline(name, scene, jobs, nrays, nrefl, hrtf, contexts=4, repeats=3
 
 def main():
     results = []
+    if os.environ.get("CONFIG_BENCH_ONLY") == "c5":      # the C5 pipeline leg alone, a few times (CONFIG_BENCH_OWN_SCENES=1: a scene copy per context)
+        hall, _ = scenes.concert_hall(30000)
+        src, mic = scenes.source_mic_pairs(64, seed=0)
+        for _ in range(3):
+            r = native_pipeline("C5 per-GPU share: 8 pairs, 100k rays x 128, HRTF", hall, [(tuple(map(float, mic[p])), tuple(map(float, src[p]))) for p in range(8)], 100000, 128, True, contexts=4)
+            print("%s: %.3f ms per IR" % (r["config"], r["ms_per_ir"]))
+        return
     # round 4: the configurations through the pipeline behind the C-ABI, each in a process state of its own as far as this tool goes
     # (measured first: a leg that runs after the one-context legs below reads 10-20 % slower on the same box)
     hall, _ = scenes.concert_hall(30000)
