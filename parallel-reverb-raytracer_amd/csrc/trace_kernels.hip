@@ -403,14 +403,16 @@ __device__ __forceinline__ int scalar_popcount(unsigned long long mask)
     return n;
 }
 
-// Closest-hit job loop with a per-iteration MAJORITY VOTE over the wave's 16 quads (path_kernel, RVB_PATH_JOBS=2).
+// Closest-hit job loop with SCHEDULED step kinds over the wave's 16 quads (path_kernel, RVB_PATH_JOBS=2).
 // A quad is in one of four states, all encoded in `ref`: at a node (bit 31 clear), at a leaf (bit 31 set), query
 // finished (NONE), out of jobs (IDLE).  The while-while loop above runs node steps until the LAST quad has reached a
 // leaf, so on incoherent rays (every bounce after the first) only ~7 of 16 quads do useful work in a node step.  Here
-// every iteration executes ONE step kind — the one most quads are waiting for (ties: the cheaper kind) — for the
-// quads in that state; the others keep their state.  Host replay on workload C2 (tools/travsim.cpp): wave-level node
-// steps per bounce 37 -> 28, quads active per node step 6.7 -> 8.9, wave instructions per bounce -13 % before the
-// vote's own cost: three compares into SGPR masks and scalar popcounts per iteration.
+// a step kind is executed for the quads in that state while the others keep theirs.  Rounds 1-3 chose the kind by a
+// majority vote per iteration (host replay on workload C2, tools/travsim.cpp: wave-level node steps per bounce 37 -> 28,
+// quads active per node step 6.7 -> 8.9, wave instructions per bounce -13 %); round 4 replaced the vote by a fixed
+// cycle with thresholds (node step, leaf step if a third of the live lanes wait for one, shading step if a quarter do:
+// 27.6 + 4.8 + 2.4 -> 22.0 + 5.7 + 3.8 steps per 16 ray-bounces, tools/travforms.cpp) — see traverse_pairs_vote,
+// "THE SCHEDULE", for the measurements.  (The function names keep the word `vote`.)
 template <class Job>
 __device__ __forceinline__ void traverse_jobs_vote(const SceneDev & sc, uint32_t * __restrict__ stack, Job & job,
                                                    lds_float4_ptr lds_nodes = nullptr)
@@ -599,7 +601,7 @@ __device__ __forceinline__ void traverse_pairs_vote(const SceneDev & sc, uint32_
         ix = clamp_inv(d.x); iy = clamp_inv(d.y); iz = clamp_inv(d.z);            \
         oix = o.x * ix; oiy = o.y * iy; oiz = o.z * iz;                           \
         selx = slab_selector(ix); sely = slab_selector(iy); selz = slab_selector(iz); \
-        best_key = NO_HIT_KEY; RVB_PAIR_EMPTY(); ref = 0; RVB_PAIR_LIMIT();                                   \
+        best_key = NO_HIT_KEY; RVB_PAIR_EMPTY(); ref = 0; RVB_PAIR_LIMIT();       \
     }
 #if RVB_STAMPS
     // diagnostic builds.  -DRVB_STAMPS=1: where a wave's cycles go — [0] vote, [1] node step until its two loads are back, [2] the rest of the
@@ -612,7 +614,6 @@ __device__ __forceinline__ void traverse_pairs_vote(const SceneDev & sc, uint32_
     t_c = t_loop;
 #endif
     if (job.next(o, d, tmax)) RVB_RESET_QUERY()
-    // lanes that carry a ray (not IDLE): changes in shading steps only
     int n_active = 0;                    // lanes that carry a ray (not IDLE): changes in shading steps only
     // the three step kinds of the loop (inlined where the schedule below calls them)
     auto leaf_step = [&]() {
